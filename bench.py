@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""Headline benchmark: SQP iterations/sec (whole node), indy7 N=32 batch=1024 per GPU, figure-8 tracking (BASELINE.json, config C2/C4).
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One step = one pass of the hot path over one batch: reset_dual() + reset_rho() + a full `BSQP::solve` (max_sqp_iters = 10, solve_ratio = 1,
+DEFAULT_SOLVER_PARAMS otherwise) on B = 1024 trajectories per GPU, inputs already resident in HBM, plus -- for N > 1 -- the
+RCCL all_gather of iterates and merits over xGMI.  value = sum over ranks of B * iterations / wall time (max over ranks).
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md, chip-level parameters)
+FP32_PEAK_TFLOPS = 157.3   # vector fp32 spec
+
+
+def stage_bytes(nq, N):
+    """Algorithmic HBM bytes per trajectory and launch of each kernel family (DESIGN.md section 'kernels'): compulsory reads + writes of the
+    buffers that cross the kernel boundary, each counted once."""
+    nx, nu = 2 * nq, nq
+    traj = (nx + nu) * N - nu
+    kkt_blocks = (N - 1) * (3 * nq * nq + nq * nq + nq + nu + nx + nu + nx) + (nq * nq + nq + nx) + nx  # D,Qq,Qd,Rd,q,r,c (+terminal, c_0)
+    S = 3 * nx * nx * N
+    vec = (N + 2) * nx
+    f = 4
+    return {
+        "kkt": f * (traj + 6 * N + 6 + nx + kkt_blocks),
+        "schur": f * (kkt_blocks + 1 + (N - 1) * (2 * nx * nx + nx * nx) + nx * nx * 2 + vec + N * (nq * nq + nq) + (N - 1) * nu      # schur: S rows, Pdiag, gamma, inverses
+                      + (N - 1) * (3 * nx * nx + 2 * nx * nx)),                                                                      # stair: 2 Pdiag + phi in, 2 blocks out
+        "pcg": f * (2 * S + 3 * vec + 2),
+        "dz": f * (2 * vec // 1 + (N - 1) * 3 * nq * nq + N * (nq * nq + nq + nx) + (N - 1) * 2 * nu + 2 * traj),
+        "merit": f * (8 * (2 * traj + 6 * N + nx + 6 + 2)),
+        "line_search": f * (3 * traj + 8 + 6),
+    }
+
+
+def usable_cores():
+    """Host threads this process may actually use: affinity mask, capped by the cgroup CPU quota when there is one."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = max(1, min(n, int(float(q) / float(per))))
+    except Exception:
+        pass
+    return n
+
+
+def cpu_baseline(plant, N, params, dt, sample_b):
+    """The CPU oracle (a C port of the reference's algorithm, oracle/gato_oracle.c) on this box's host cores, bounded sample:
+    trajectories are independent, so `cores` single-threaded oracle solvers each take a contiguous slice of the sample (no barriers)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from gato_amd.bsqp.workloads import fig8_problem
+    from oracle.oracle import OracleSolver
+    cores = min(usable_cores(), 128, sample_b)
+    per = sample_b // cores
+    sample_b = per * cores
+    pr = fig8_problem(plant, N, sample_b)
+    solvers = [OracleSolver(plant, N, per, dt=dt, threads=1, **params) for _ in range(cores)]
+
+    def run(i):
+        sl = slice(i * per, (i + 1) * per)
+        return solvers[i].solve(pr["xu"][sl], dt, pr["x_s"][sl], pr["ref"][sl])["iters_done"]
+
+    warm = OracleSolver(plant, N, 1, dt=dt, threads=1, **params)
+    warm.solve(pr["xu"][:1], dt, pr["x_s"][:1], pr["ref"][:1])   # library load, page faults
+    with ThreadPoolExecutor(cores) as ex:
+        list(ex.map(lambda i: i, range(cores)))
+        t0 = time.perf_counter()
+        iters = list(ex.map(run, range(cores)))   # ctypes releases the GIL inside orc_solve
+        t = time.perf_counter() - t0
+    rate = per * sum(iters) / t
+    t0 = time.perf_counter()
+    o1 = solvers[0].solve(pr["xu"][:per], dt, pr["x_s"][:per], pr["ref"][:per])
+    t1 = time.perf_counter() - t0
+    single = per * o1["iters_done"] / t1
+    return {"value": rate, "unit": "traj-SQP-iter/s", "cores": cores, "kind": "port",
+            "sample": "first %d trajectories of the same workload, %d SQP iterations each, %d single-threaded oracle solvers side by side "
+                      "(%.2f s); one thread alone: %.0f traj-SQP-iter/s" % (sample_b, iters[0], cores, t, single),
+            "single_core_value": single}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--plant", default="indy7")
+    ap.add_argument("--knots", type=int, default=32)
+    ap.add_argument("--batch", type=int, default=1024, help="trajectories per GPU")
+    ap.add_argument("--sqp-iters", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=1024)
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (a.gpus, world, a.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (the product has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from gato_amd._lib import NativeSolver
+    from gato_amd.bsqp.config import DEFAULT_SOLVER_PARAMS
+    from gato_amd.bsqp.workloads import fig8_problem
+    plant, N, B, dt = a.plant, a.knots, a.batch, 0.01
+    params = dict(DEFAULT_SOLVER_PARAMS, max_sqp_iters=a.sqp_iters)
+    pr = fig8_problem(plant, N, B, batch_offset=rank * B)          # rank r owns rows [r*B, (r+1)*B) of the global batch
+    solver = NativeSolver(plant, N, B, dt=dt, **params)
+    xu0 = torch.from_numpy(pr["xu"]).to(dev)
+    xu = torch.empty_like(xu0)
+    x_s = torch.from_numpy(pr["x_s"]).to(dev)
+    ref = torch.from_numpy(pr["ref"]).to(dev)
+    merit = torch.empty(B, dtype=torch.float32, device=dev)
+    if world > 1:
+        g_xu = [torch.empty_like(xu) for _ in range(world)]
+        g_merit = [torch.empty_like(merit) for _ in range(world)]
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        solver.reset_async(True, True, stream)  # reset_dual() + reset_rho(), stream-ordered
+        xu.copy_(xu0)
+        solver.solve_device(xu.data_ptr(), dt, x_s.data_ptr(), ref.data_ptr(), stream)
+        solver.copy_final_merit_device(merit.data_ptr(), stream)
+        if world > 1:
+            dist.all_gather(g_xu, xu)           # iterates: B x TRAJ fp32 per rank over xGMI
+            dist.all_gather(g_merit, merit)     # costs: B fp32 per rank
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    sync()
+    stage_acc = {}
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    sync()
+    t = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([t], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        t = float(tt.item())
+
+    st = solver.stats()
+    iters = st["iters_done"]
+    # kernel durations measured live: one extra (untimed) step with hipEvents on the solver's stream around each kernel family
+    solver.set_profiling(True)
+    step()
+    sync()
+    stage_acc = solver.stage_times_us()
+    solver.set_profiling(False)
+    ok = bool(np.all(np.isfinite(st["final_merit"])) and np.all(st["final_merit"] < st["initial_merit"]))
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    value = world * B * iters * a.steps / t
+    launches = {"kkt": iters, "schur": iters, "pcg": iters, "dz": iters, "merit": iters + 2, "line_search": iters}
+    per_launch_us = {k: stage_acc[k] / max(1, launches[k]) for k in launches}
+    dom = max(per_launch_us, key=lambda k: stage_acc[k])
+    sb = stage_bytes(NativeSolver_nq(plant), N)
+    dom_bytes = sb[dom] * B * (1.0 if dom != "merit" else (8 * iters + 2) / 8.0 / (iters + 2))
+    achieved = dom_bytes / (per_launch_us[dom] * 1e-6) / 1e9
+    traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_summary.json")
+    if os.path.exists(pmc_path):
+        try:
+            traffic = json.load(open(pmc_path)).get(dom, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    line = {
+        "metric": "SQP iterations/sec (whole node), indy7 N=32 batch=1024, 1/2/4/8 MI355X",
+        "value": value, "unit": "trajectory-SQP-iterations/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": 1e3 * t / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "%s N=%d batch=%d per GPU (global %d), figure-8 end-effector tracking, %d SQP iterations per solve, "
+                               "DEFAULT_SOLVER_PARAMS (max_pcg 200, pcg_tol 1e-4, rho 0.01), reset_dual+reset_rho per solve"
+                               % (plant, N, B, world * B, iters),
+                   "plant": plant, "knot_points": N, "batch_per_gpu": B, "global_batch": world * B, "sqp_iters_per_solve": int(iters),
+                   "mean_pcg_iters": float(st["pcg_iters_all"].mean()), "parallelism": "batch-sharded x%d, all_gather of iterates" % world},
+        "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": traffic, "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_us": per_launch_us[dom],
+                     "stage_us_per_solve": {k: round(v, 1) for k, v in stage_acc.items()},
+                     "whole_iteration": {"algorithmic_bytes_per_traj_iter": 268e3 if (plant, N) == ("indy7", 32) else None,
+                                         "hbm_frac": (268e3 * value / world / 1e9 / HBM_PEAK_GBS) if (plant, N) == ("indy7", 32) else None}},
+        "solution_ok": ok,
+    }
+    if not a.no_cpu_baseline and world == 1:
+        line["cpu_baseline"] = cpu_baseline(plant, N, params, dt, a.cpu_sample)
+        line["cpu_baseline"]["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
+    print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def NativeSolver_nq(plant):
+    return {"indy7": 6, "iiwa14": 7}[plant]
+
+
+if __name__ == "__main__":
+    main()

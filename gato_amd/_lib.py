@@ -1,0 +1,290 @@
+"""ctypes binding of include/gato_abi.h (libgato_hip.so).  Fails loudly when the HIP library is missing: there is no CPU fallback."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "csrc", "libgato_hip.so")
+PLANTS = {"indy7": 0, "iiwa14": 1}
+NQ = {"indy7": 6, "iiwa14": 7}
+
+SYMBOLS = [
+    "gato_default_params", "gato_dims", "gato_create", "gato_destroy", "gato_solve", "gato_solve_device", "gato_get_counts",
+    "gato_get_sqp_iters", "gato_get_kkt_converged", "gato_get_final_merit", "gato_get_initial_merit", "gato_get_pcg_iters",
+    "gato_get_ls_min_merit", "gato_get_ls_step_size", "gato_set_f_ext_batch", "gato_set_rho_penalty_batch", "gato_set_drho_batch",
+    "gato_set_mu_batch", "gato_set_pcg_tol_batch", "gato_reset_dual", "gato_reset_rho", "gato_set_rho_adaptation", "gato_sim_forward",
+    "gato_ee_pos", "gato_debug_read", "gato_debug_write", "gato_debug_stage", "gato_set_profiling", "gato_get_stage_times_us",
+    "gato_last_error", "gato_version", "gato_reset_async", "gato_copy_final_merit_device",
+]
+
+
+class GatoParams(C.Structure):
+    _fields_ = [("dt", C.c_float), ("max_sqp_iters", C.c_uint32), ("kkt_tol", C.c_float), ("max_pcg_iters", C.c_uint32),
+                ("pcg_tol", C.c_float), ("solve_ratio", C.c_float), ("mu", C.c_float), ("q_cost", C.c_float), ("qd_cost", C.c_float),
+                ("u_cost", C.c_float), ("N_cost", C.c_float), ("q_lim_cost", C.c_float), ("vel_lim_cost", C.c_float),
+                ("ctrl_lim_cost", C.c_float), ("rho", C.c_float)]
+
+
+class GatoError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Loads libgato_hip.so.  torch (when installed) is imported FIRST so that both share torch's bundled libamdhip64 instead of
+    loading a second HIP runtime into the process."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GatoError("libgato_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C gato_amd/csrc`."
+                        % LIB_PATH)
+    if "torch" not in sys.modules and os.environ.get("GATO_NO_TORCH", "0") != "1":
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
+    L = C.CDLL(LIB_PATH)
+    fp, ip, vp = C.POINTER(C.c_float), C.POINTER(C.c_int32), C.c_void_p
+    L.gato_default_params.argtypes = [C.POINTER(GatoParams)]
+    L.gato_default_params.restype = None
+    L.gato_dims.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.gato_create.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(GatoParams), C.POINTER(vp)]
+    L.gato_destroy.argtypes = [vp]
+    L.gato_solve.argtypes = [vp, fp, C.c_float, fp, fp, C.POINTER(C.c_double)]
+    L.gato_solve_device.argtypes = [vp, vp, C.c_float, vp, vp, vp]
+    L.gato_get_counts.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    for n in ("gato_get_sqp_iters", "gato_get_kkt_converged", "gato_get_pcg_iters"):
+        getattr(L, n).argtypes = [vp, ip]
+    for n in ("gato_get_final_merit", "gato_get_initial_merit", "gato_get_ls_min_merit", "gato_get_ls_step_size", "gato_set_f_ext_batch",
+              "gato_set_mu_batch", "gato_set_pcg_tol_batch"):
+        getattr(L, n).argtypes = [vp, fp]
+    for n in ("gato_set_rho_penalty_batch", "gato_set_drho_batch"):
+        getattr(L, n).argtypes = [vp, fp, C.c_int]
+    for n in ("gato_reset_dual", "gato_reset_rho"):
+        getattr(L, n).argtypes = [vp]
+    L.gato_set_rho_adaptation.argtypes = [vp, C.c_int]
+    L.gato_sim_forward.argtypes = [vp, fp, fp, fp, C.c_float]
+    L.gato_ee_pos.argtypes = [vp, fp, C.c_int, fp]
+    L.gato_debug_read.argtypes = [vp, C.c_char_p, fp, C.c_uint64, C.POINTER(C.c_uint64)]
+    L.gato_debug_write.argtypes = [vp, C.c_char_p, fp, C.c_uint64]
+    L.gato_debug_stage.argtypes = [vp, C.c_int, fp, C.c_float, fp, fp, fp]
+    L.gato_set_profiling.argtypes = [vp, C.c_int]
+    L.gato_get_stage_times_us.argtypes = [vp, C.POINTER(C.c_double)]
+    L.gato_reset_async.argtypes = [vp, C.c_int, C.c_int, vp]
+    L.gato_copy_final_merit_device.argtypes = [vp, vp, vp]
+    L.gato_last_error.restype = C.c_char_p
+    L.gato_version.restype = C.c_char_p
+    _lib = L
+    return L
+
+
+def _chk(rc):
+    if rc != 0:
+        raise GatoError("libgato_hip: status %d: %s" % (rc, load().gato_last_error().decode()))
+
+
+def _f32(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if shape is not None:
+        a = a.reshape(shape)
+    return a
+
+
+def _p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+PARAM_ORDER = [f[0] for f in GatoParams._fields_]
+STAGES = {"merit8": 0, "kkt": 1, "schur": 2, "pcg": 3, "dz": 4, "line_search": 5, "merit1": 6}
+
+
+class NativeSolver:
+    """Owns one `GatoSolver*`.  Method names follow PyBSQP<T,B> (python/bindings.cu:224-237)."""
+
+    def __init__(self, plant, knot_points, batch_size, **params):
+        L = load()
+        if plant not in PLANTS:
+            raise ValueError("unknown plant %r" % (plant,))
+        self.plant, self.N, self.B = plant, int(knot_points), int(batch_size)
+        self.nq = NQ[plant]
+        self.nx, self.nu = 2 * self.nq, self.nq
+        self.traj = (self.nx + self.nu) * self.N - self.nu
+        p = GatoParams()
+        L.gato_default_params(C.byref(p))
+        for k, v in params.items():
+            if k not in PARAM_ORDER:
+                raise TypeError("unknown solver parameter %r" % k)
+            setattr(p, k, v)
+        self.params = p
+        h = C.c_void_p()
+        _chk(L.gato_create(PLANTS[plant], self.N, self.B, C.byref(p), C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            load().gato_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- solve ----
+    def solve(self, xu, timestep, x_s, ref):
+        """PyBSQP::solve (bindings.cu:68-148): returns the same dict (XU, sqp_time_us, sqp_iters, kkt_converged, final_merit,
+        initial_merit, ls_num_iters, pcg_times_us, pcg_iters, ls_min_merit, ls_step_size)."""
+        L = load()
+        xu = np.array(xu, dtype=np.float32, order="C").reshape(self.B, self.traj)
+        x_s = _f32(x_s, (self.B, self.nx))
+        ref = _f32(ref, (self.B, 6 * self.N))
+        t = C.c_double(0.0)
+        _chk(L.gato_solve(self.h, _p(xu), float(timestep), _p(x_s), _p(ref), C.byref(t)))
+        out = self.stats()
+        out["XU"] = xu
+        out["sqp_time_us"] = t.value
+        return out
+
+    def solve_device(self, d_xu, timestep, d_x_s, d_ref, stream=0):
+        """BSQP::solve on raw device pointers (ints), asynchronous on `stream`."""
+        _chk(load().gato_solve_device(self.h, C.c_void_p(d_xu), float(timestep), C.c_void_p(d_x_s), C.c_void_p(d_ref), C.c_void_p(stream)))
+
+    def reset_async(self, dual=True, rho=True, stream=0):
+        _chk(load().gato_reset_async(self.h, int(dual), int(rho), C.c_void_p(stream)))
+
+    def copy_final_merit_device(self, d_out, stream=0):
+        _chk(load().gato_copy_final_merit_device(self.h, C.c_void_p(d_out), C.c_void_p(stream)))
+
+    def stats(self):
+        L = load()
+        B = self.B
+        it, ls = C.c_uint32(0), C.c_uint32(0)
+        _chk(L.gato_get_counts(self.h, C.byref(it), C.byref(ls)))
+        it, ls = it.value, ls.value
+        sqp_iters = np.zeros(B, np.int32)
+        conv = np.zeros(B, np.int32)
+        fm = np.zeros(B, np.float32)
+        im = np.zeros(B, np.float32)
+        pcg = np.zeros((max(it, 1), B), np.int32)
+        mm = np.zeros((max(ls, 1), B), np.float32)
+        ss = np.zeros((max(ls, 1), B), np.float32)
+        ip = C.POINTER(C.c_int32)
+        _chk(L.gato_get_sqp_iters(self.h, sqp_iters.ctypes.data_as(ip)))
+        _chk(L.gato_get_kkt_converged(self.h, conv.ctypes.data_as(ip)))
+        _chk(L.gato_get_final_merit(self.h, _p(fm)))
+        _chk(L.gato_get_initial_merit(self.h, _p(im)))
+        _chk(L.gato_get_pcg_iters(self.h, pcg.ctypes.data_as(ip)))
+        _chk(L.gato_get_ls_min_merit(self.h, _p(mm)))
+        _chk(L.gato_get_ls_step_size(self.h, _p(ss)))
+        return {
+            "sqp_iters": sqp_iters, "kkt_converged": conv, "final_merit": fm, "initial_merit": im, "ls_num_iters": int(ls),
+            "pcg_times_us": np.zeros(ls, np.float32),       # always 0 in the reference too (bsqp.cuh:138)
+            "pcg_iters": pcg[:ls],                            # the reference truncates to the line searches done (bindings.cu:111-128)
+            "ls_min_merit": mm[:ls], "ls_step_size": ss[:ls],
+            "iters_done": int(it), "pcg_iters_all": pcg[:it],
+        }
+
+    # ---- setters ----
+    def set_f_ext_batch(self, f):
+        _chk(load().gato_set_f_ext_batch(self.h, _p(_f32(f, (self.B, 6)))))
+
+    def set_rho_penalty_batch(self, v, set_as_reset_default=True):
+        _chk(load().gato_set_rho_penalty_batch(self.h, _p(_f32(v, (self.B,))), int(bool(set_as_reset_default))))
+
+    def set_drho_batch(self, v, set_as_reset_default=True):
+        _chk(load().gato_set_drho_batch(self.h, _p(_f32(v, (self.B,))), int(bool(set_as_reset_default))))
+
+    def set_mu_batch(self, v):
+        _chk(load().gato_set_mu_batch(self.h, _p(_f32(v, (self.B,)))))
+
+    def set_pcg_tol_batch(self, v):
+        _chk(load().gato_set_pcg_tol_batch(self.h, _p(_f32(v, (self.B,)))))
+
+    def reset_dual(self):
+        _chk(load().gato_reset_dual(self.h))
+
+    def reset_rho(self):
+        _chk(load().gato_reset_rho(self.h))
+
+    def set_rho_adaptation(self, enabled):
+        _chk(load().gato_set_rho_adaptation(self.h, int(bool(enabled))))
+
+    def sim_forward(self, xk, uk, dt):
+        out = np.zeros((self.B, self.nx), np.float32)
+        _chk(load().gato_sim_forward(self.h, _p(out), _p(_f32(xk, (self.nx,))), _p(_f32(uk, (self.nu,))), float(dt)))
+        return out
+
+    def ee_pos(self, q):
+        q = _f32(q).reshape(-1, self.nq)
+        out = np.zeros((q.shape[0], 3), np.float32)
+        _chk(load().gato_ee_pos(self.h, _p(q), q.shape[0], _p(out)))
+        return out
+
+    # ---- profiling / debug ----
+    def set_profiling(self, enabled):
+        _chk(load().gato_set_profiling(self.h, int(bool(enabled))))
+
+    def stage_times_us(self):
+        out = (C.c_double * 7)()
+        _chk(load().gato_get_stage_times_us(self.h, out))
+        return dict(zip(["merit", "kkt", "schur", "pcg", "dz", "line_search", "total"], list(out)))
+
+    def read(self, name):
+        n = C.c_uint64(0)
+        _chk(load().gato_debug_read(self.h, name.encode(), None, 0, C.byref(n)))
+        out = np.zeros(n.value, np.float32)
+        _chk(load().gato_debug_read(self.h, name.encode(), _p(out), n.value, None))
+        return out
+
+    def write(self, name, arr):
+        a = _f32(arr).reshape(-1)
+        _chk(load().gato_debug_write(self.h, name.encode(), _p(a), a.size))
+
+    def stage(self, stage, xu, timestep, x_s, ref):
+        xu = np.array(xu, dtype=np.float32, order="C").reshape(self.B, self.traj)
+        x_s = _f32(x_s, (self.B, self.nx))
+        ref = _f32(ref, (self.B, 6 * self.N))
+        _chk(load().gato_debug_stage(self.h, STAGES[stage], _p(xu), float(timestep), _p(x_s), _p(ref), None))
+        return xu
+
+    # expansion of the compact KKT storage into the reference's dense blocks (for stage comparisons)
+    def dense_kkt(self, dt):
+        B, N, nq, nx, nu = self.B, self.N, self.nq, self.nx, self.nu
+        D = self.read("D").reshape(B, N, 3 * nq, nq)           # [c][r] col-major nq x 3nq
+        h2 = np.float32(0.5 * float(np.float32(dt)) * float(np.float32(dt)))
+        dtf = np.float32(dt)
+        A = np.zeros((B, N, nx, nx), np.float32)                # A[b,k,c,r] (col-major blocks like the reference's memory)
+        Bm = np.zeros((B, N, nu, nx), np.float32)
+        eye = np.eye(nq, dtype=np.float32)
+        Dq, Dd, Mi = D[:, :, :nq], D[:, :, nq:2 * nq], D[:, :, 2 * nq:]
+        A[:, :, :nq, :nq] = eye + h2 * Dq
+        A[:, :, :nq, nq:] = dtf * Dq
+        A[:, :, nq:, :nq] = dtf * eye + h2 * Dd
+        A[:, :, nq:, nq:] = eye + dtf * Dd
+        Bm[:, :, :, :nq] = h2 * Mi
+        Bm[:, :, :, nq:] = dtf * Mi
+        A[:, N - 1] = 0
+        Bm[:, N - 1] = 0
+
+        def blk(qq, dd):
+            out = np.zeros((B, N, nx, nx), np.float32)
+            out[:, :, :nq, :nq] = qq.reshape(B, N, nq, nq)
+            idx = np.arange(nq)
+            out[:, :, nq + idx, nq + idx] = dd.reshape(B, N, nq)
+            return out
+
+        def dg(d):
+            out = np.zeros((B, N, nu, nu), np.float32)
+            idx = np.arange(nu)
+            out[:, :, idx, idx] = d.reshape(B, N, nu)
+            return out
+
+        return dict(A=A, B=Bm, Q=blk(self.read("Qq"), self.read("Qd")), R=dg(self.read("Rd")), q=self.read("q").reshape(B, N, nx),
+                    r=self.read("r").reshape(B, N, nu), c=self.read("c").reshape(B, N, nx),
+                    Qinv=blk(self.read("Qqi"), self.read("Qdi")), Rinv=dg(self.read("Rdi")))

@@ -1,0 +1,1054 @@
+// kernels.hpp -- CDNA4 (gfx950) kernels of the batched SQP iteration.  Included once per plant by solver.hip.
+//
+// Mapping (MI355X-first, not the reference's block-per-knot scheme):
+//   * assembly / merit / dz kernels: ONE LANE per (trajectory, knot[, alpha]) problem, 64 problems per wavefront, everything
+//     for that problem in registers (rbd.hpp); cross-knot sums (merit) are wave butterflies -> deterministic, no float atomics;
+//   * PCG: one workgroup per trajectory, one thread per row of the block-tridiagonal system, the thread's rows of S and P^-1
+//     live in REGISTERS for the whole solve (read from HBM exactly once; the reference re-reads both from global memory on
+//     every PCG iteration, pcg.cuh:100,119), vectors exchanged through LDS;
+//   * the SQP loop has no host round trip: convergence counting and the solve_ratio early exit run on the device (Ctrl).
+//
+// Global layouts are trajectory-major like the reference's (linalg.cuh:545-672) so xu / x_s / ref / lambda / S / P^-1 / gamma are
+// byte-compatible with its buffers; KKT blocks are stored COMPACT:
+//   D    [b][k][3 nq^2]   = [dqdd/dq | dqdd/dqd | M^-1] col-major nq x 3nq   (A_k, B_k are functions of D and dt: A_elem/B_elem)
+//   Qq   [b][k][nq^2], Qd [b][k][nq]   Q_k = blkdiag(Qq, diag(Qd))   (the cost Hessian has no other non-zeros, indy7_plant.cuh:375-408)
+//   Rd   [b][k][nu]                     R_k = diag(Rd)
+//   q [b][k][nx], r [b][k][nu], c [b][k][nx]; after schur: Qqi/Qdi/Rdi hold the inverses (separate buffers: no RAW hazard)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rbd.hpp"
+
+namespace gato {
+
+constexpr int NUM_ALPHAS = 8;        // settings.h:16
+constexpr float RHO_FACTOR = 1.2f;   // settings.h:20
+constexpr float RHO_MIN = 1e-8f;     // settings.h:21
+constexpr float RHO_MAX = 10.0f;     // settings.h:22
+
+struct Costs {
+    float q_cost, qd_cost, u_cost, N_cost, q_lim_cost, vel_lim_cost, ctrl_lim_cost;
+};
+
+// device-side SQP loop control (replaces the host loop of bsqp.cuh:137-176)
+struct Ctrl {
+    uint32_t done;        // set once the solve_ratio exit fired: every later kernel of this solve is a no-op
+    uint32_t iters_done;  // outer iterations executed (kkt..dz ran)
+    uint32_t ls_done;     // line searches executed
+    uint32_t pad;
+};
+
+struct Buffers {
+    // problem (borrowed for the solve)
+    float* xu; const float* x_s; const float* ref;
+    // persistent per-trajectory state
+    float *lambda, *rho, *drho, *mu, *pcg_tol, *f_ext;
+    // KKT (compact) + Schur
+    float *D, *Qq, *Qd, *Rd, *q, *r, *c, *Qqi, *Qdi, *Rdi, *S, *Pinv, *gamma, *dz;
+    float *merit, *merit_cur, *step;
+    int32_t* converged; uint32_t* pcg_iters;
+    // per-iteration stats [max_iters][B]
+    int32_t* st_pcg_iters; float *st_min_merit, *st_step;
+    Ctrl* ctrl;
+    uint32_t* num_solved;  // [max_iters]: trajectories counted as solved after outer iteration i (bsqp.cuh:142-163)
+};
+
+// ---- integrator pieces (integrator.cuh:34-37, 143-184), INTEGRATOR_TYPE 2 ----------------------------------------------
+GATO_DEV float half_dt_sq(float dt) { return (float)(0.5 * (double)dt * (double)dt); }
+
+template<int NQ> GATO_DEV float A_elem(const float* D, int r, int c, float dt, float h2)
+{
+    // D[c*NQ + r'] = d qdd_r' / d x_c, c < 2 NQ
+    const float d = D[c * NQ + (r % NQ)];
+    float val = (r == c) ? 1.0f : 0.0f;
+    if (r < NQ) {
+        if (c >= NQ && r == c - NQ) val += dt;
+        val += h2 * d;
+    } else {
+        val += dt * d;
+    }
+    return val;
+}
+template<int NQ> GATO_DEV float B_elem(const float* D, int r, int c, float dt, float h2)
+{
+    const float d = D[2 * NQ * NQ + c * NQ + (r % NQ)];
+    return (r < NQ) ? h2 * d : dt * d;
+}
+
+// ---- barrier functions (indy7_plant.cuh:130-148, iiwa14_plant.cuh:104-155) -------------------------------------------------
+GATO_DEV float joint_barrier(float q, float lo, float hi)
+{
+    float dmin = q - lo, dmax = hi - q;
+    dmin = (dmin <= 1e-10) ? (float)1e-10 : dmin;
+    dmax = (dmax <= 1e-10) ? (float)1e-10 : dmax;
+    return -logf(dmin) - logf(dmax);
+}
+template<int MODE> GATO_DEV float joint_barrier_grad(float q, float lo, float hi)
+{
+    float dmin = q - lo, dmax = hi - q;
+    if constexpr (MODE == 0) {
+        dmin = (dmin <= 1e-6) ? (float)1e-6 : dmin;
+        dmax = (dmax <= 1e-6) ? (float)1e-6 : dmax;
+        return (-1 / dmin) + (1 / dmax);
+    } else {
+        const float eps = 1e-6f;
+        if (dmin >= 0.f) { if (dmin < eps) dmin = eps; } else { if (dmin > -eps) dmin = -eps; }
+        if (dmax >= 0.f) { if (dmax < eps) dmax = eps; } else { if (dmax > -eps) dmax = -eps; }
+        return (-1.0f / dmin) + (1.0f / dmax);
+    }
+}
+GATO_DEV float joint_barrier_hess(float q, float lo, float hi)
+{
+    float dmin = q - lo, dmax = hi - q;
+    const float eps = 1e-6f;
+    float amin = dmin >= 0.f ? dmin : -dmin, amax = dmax >= 0.f ? dmax : -dmax;
+    if (amin < eps) amin = eps;
+    if (amax < eps) amax = eps;
+    return 1.0f / (amin * amin) + 1.0f / (amax * amax);
+}
+
+// sum over aligned groups of `seg` consecutive threads (seg = power of two, <= blockDim); every thread gets the group's sum
+GATO_DEV float seg_sum(float v, int seg, float* lds_part)
+{
+    const int w = seg < 64 ? seg : 64;
+    for (int off = w >> 1; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    if (seg > 64) {
+        const int wave = threadIdx.x >> 6, per = seg >> 6;
+        if ((threadIdx.x & 63) == 0) lds_part[wave] = v;
+        __syncthreads();
+        const int base = (wave / per) * per;
+        float s = 0.f;
+        for (int i = 0; i < per; i++) s += lds_part[base + i];
+        v = s;
+    }
+    return v;
+}
+
+// =========================================================================================================================
+// merit: M_b(alpha) = sum_k cost_k + mu_b (sum_k |x_{k+1} - f(x_k,u_k)|_1 + |x_0 - x_s|_1) at xu + alpha dz   (merit.cuh:17-92)
+// one lane per (b, alpha, k); grid-stride free: thread g -> k = g % N, a = (g / N) % NA, b = g / (N NA)
+// =========================================================================================================================
+template<class M, int NA>
+__global__ __launch_bounds__(256) void merit_kernel(Buffers bf, Costs cw, int N, int B, float dt, int use_dz, int sqp_iter, float thresh,
+                                                    float* __restrict__ out)
+{
+    constexpr int NQ = M::NQ, NX = 2 * NQ, NU = NQ, KS = NX + NU;
+    __shared__ float part[4];
+    if (sqp_iter >= 0) {
+        if (bf.ctrl->done) return;
+        if ((float)bf.num_solved[sqp_iter] >= thresh) return;  // loop breaks before the line search (bsqp.cuh:165)
+    }
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    const int k = g % N, ai = (g / N) % NA;
+    int b = g / (N * NA);
+    const bool live = b < B;
+    if (!live) b = B - 1;
+    const int traj = KS * N - NU;
+    const float alpha = (float)(1.0 / (double)(1 << ai));
+    const float* xu = bf.xu + (size_t)b * traj + (size_t)k * KS;
+    const float* dz = bf.dz + (size_t)b * traj + (size_t)k * KS;
+    const bool last = (k == N - 1);
+
+    float s[2 * NX + NU];
+#pragma unroll
+    for (int i = 0; i < 2 * NX + NU; i++) {
+        const bool in = (i < NX) || !last;
+        float v = in ? xu[i] : 0.f;
+        if (use_dz && in) v += alpha * dz[i];
+        s[i] = v;
+    }
+    const float* ref = bf.ref + (size_t)b * 6 * N + 6 * k;
+
+    RBD<M> d;
+    d.set_q(s);
+    // ---- cost (plant::trackingcost, indy7_plant.cuh:266-318)
+    float e[3];
+    d.ee_pos(e);
+    float cost = 0.f;
+#pragma unroll
+    for (int i = 0; i < NQ; i++) {
+        const float err = s[NQ + i];
+        float t = 0.5f * cw.qd_cost * err * err;
+        t += cw.q_lim_cost * joint_barrier(s[i], M::Q_LIM[i][0], M::Q_LIM[i][1]);
+        if (cw.vel_lim_cost != 0.f) t += cw.vel_lim_cost * joint_barrier(err, M::V_LIM[i][0], M::V_LIM[i][1]);
+        cost += t;
+    }
+    if (!last) {
+#pragma unroll
+        for (int i = 0; i < NU; i++) {
+            const float err = s[NX + i];
+            float t = 0.5f * cw.u_cost * err * err;
+            if (cw.ctrl_lim_cost != 0.f) t += cw.ctrl_lim_cost * joint_barrier(err, M::U_LIM[i][0], M::U_LIM[i][1]);
+            cost += t;
+        }
+    }
+    const float w = last ? cw.N_cost : cw.q_cost;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const float err = e[i] - ref[i];
+        cost += (float)(0.5 * (double)w * (double)err * (double)err);
+    }
+    // ---- constraint violation
+    float con = 0.f;
+    if (!last) {
+        float fe[6], qdd[NQ];
+#pragma unroll
+        for (int i = 0; i < 6; i++) fe[i] = bf.f_ext[6 * b + i];
+        d.forward_dynamics(s + NQ, s + NX, fe, qdd);
+#pragma unroll
+        for (int i = 0; i < NQ; i++) {
+            const float qdn = s[NQ + i] + dt * qdd[i];
+            const float qn = (float)((double)(s[i] + dt * s[NQ + i]) + 0.5 * (double)qdd[i] * (double)dt * (double)dt);
+            con += fabsf(s[KS + i] - qn);
+            con += fabsf(s[KS + NQ + i] - qdn);
+        }
+    } else {
+        const float* x0 = bf.xu + (size_t)b * traj;
+        const float* dz0 = bf.dz + (size_t)b * traj;
+#pragma unroll
+        for (int i = 0; i < NX; i++) {
+            float v = x0[i];
+            if (use_dz) v += alpha * dz0[i];
+            con += fabsf(v - bf.x_s[(size_t)b * NX + i]);
+        }
+    }
+    float m = cost + bf.mu[b] * con;
+    m = seg_sum(m, N, part);
+    if (live && k == 0) out[b * NA + ai] = m;
+}
+
+// =========================================================================================================================
+// KKT assembly (setup_kkt.cuh:15-108): one lane per (b,k).  k <= N-2: D_k, c_{k+1}, cost blocks of knot k; k == N-2 also the
+// terminal blocks (at x_{N-2} against ref_{N-1}, with q_cost -- SURVEY A.1/A.2); k == N-1: c_0 = x_0 - x_s.
+// =========================================================================================================================
+template<class M>
+GATO_DEV void cost_blocks(const RBD<M>& d, const Costs& cw, const float* x, const float* u, const float* ref, float* Qq, float* Qd, float* qv,
+                          float* Rd, float* rv)
+{
+    constexpr int NQ = M::NQ, MODE = M::BARRIER_MODE;
+    float e[3], Jc[NQ][3], g[NQ], bq[NQ];
+    d.ee_jac(e, Jc);
+    const float w = cw.q_cost;
+    const float e0 = e[0] - ref[0], e1 = e[1] - ref[1], e2 = e[2] - ref[2];
+#pragma unroll
+    for (int i = 0; i < NQ; i++) {
+        g[i] = (Jc[i][0] * e0 + Jc[i][1] * e1 + Jc[i][2] * e2);
+        bq[i] = joint_barrier_grad<MODE>(x[i], M::Q_LIM[i][0], M::Q_LIM[i][1]);
+        float t = g[i] * w;
+        t += cw.q_lim_cost * bq[i];
+        qv[i] = t;
+        float t2 = cw.qd_cost * x[NQ + i];
+        float dd = cw.qd_cost;
+        if (cw.vel_lim_cost != 0.f) {
+            const float bv = joint_barrier_grad<MODE>(x[NQ + i], M::V_LIM[i][0], M::V_LIM[i][1]);
+            t2 += cw.vel_lim_cost * bv;
+            if constexpr (MODE == 0) dd += cw.vel_lim_cost * bv * bv;
+            else dd += cw.vel_lim_cost * joint_barrier_hess(x[NQ + i], M::V_LIM[i][0], M::V_LIM[i][1]);
+        }
+        qv[NQ + i] = t2;
+        Qd[i] = dd;
+    }
+#pragma unroll
+    for (int i = 0; i < NQ; i++)
+#pragma unroll
+        for (int j = 0; j < NQ; j++) {
+            float val = (g[i] * g[j]) * w;
+            if constexpr (MODE == 0) {
+                val += cw.q_lim_cost * bq[i] * bq[j];
+            } else {
+                if (i == j) val += cw.q_lim_cost * joint_barrier_hess(x[i], M::Q_LIM[i][0], M::Q_LIM[i][1]);
+            }
+            Qq[i * NQ + j] = val;
+        }
+    if (Rd) {
+#pragma unroll
+        for (int i = 0; i < NQ; i++) {
+            float t = cw.u_cost * u[i];
+            float dd = cw.u_cost;
+            if (cw.ctrl_lim_cost != 0.f) {
+                const float bu = joint_barrier_grad<MODE>(u[i], M::U_LIM[i][0], M::U_LIM[i][1]);
+                t += cw.ctrl_lim_cost * bu;
+                if constexpr (MODE == 0) dd += cw.ctrl_lim_cost * bu * bu;
+                else dd += cw.ctrl_lim_cost * joint_barrier_hess(u[i], M::U_LIM[i][0], M::U_LIM[i][1]);
+            }
+            rv[i] = t;
+            Rd[i] = dd;
+        }
+    }
+}
+
+// vectorised private<->global copies.  ALIGN = a number of floats that divides every offset the pointer can take (and the
+// allocation itself is 256-byte aligned), so the widest access that is BOTH naturally aligned and divides CNT is used.
+template<int CNT, int ALIGN> constexpr int vec_width()
+{
+    return (CNT % 4 == 0 && ALIGN % 4 == 0) ? 4 : ((CNT % 2 == 0 && ALIGN % 2 == 0) ? 2 : 1);
+}
+template<int CNT, int ALIGN> GATO_DEV void store_vec(float* __restrict__ dst, const float* src)
+{
+    constexpr int W = vec_width<CNT, ALIGN>();
+    if constexpr (W == 4) {
+#pragma unroll
+        for (int i = 0; i < CNT / 4; i++) reinterpret_cast<float4*>(dst)[i] = make_float4(src[4 * i], src[4 * i + 1], src[4 * i + 2], src[4 * i + 3]);
+    } else if constexpr (W == 2) {
+#pragma unroll
+        for (int i = 0; i < CNT / 2; i++) reinterpret_cast<float2*>(dst)[i] = make_float2(src[2 * i], src[2 * i + 1]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < CNT; i++) dst[i] = src[i];
+    }
+}
+template<int CNT, int ALIGN> GATO_DEV void load_vec(float* dst, const float* __restrict__ src)
+{
+    constexpr int W = vec_width<CNT, ALIGN>();
+    if constexpr (W == 4) {
+#pragma unroll
+        for (int i = 0; i < CNT / 4; i++) {
+            const float4 v = reinterpret_cast<const float4*>(src)[i];
+            dst[4 * i] = v.x; dst[4 * i + 1] = v.y; dst[4 * i + 2] = v.z; dst[4 * i + 3] = v.w;
+        }
+    } else if constexpr (W == 2) {
+#pragma unroll
+        for (int i = 0; i < CNT / 2; i++) {
+            const float2 v = reinterpret_cast<const float2*>(src)[i];
+            dst[2 * i] = v.x; dst[2 * i + 1] = v.y;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < CNT; i++) dst[i] = src[i];
+    }
+}
+
+template<class M>
+__global__ __launch_bounds__(64) void kkt_kernel(Buffers bf, Costs cw, int N, int B, float dt)
+{
+    constexpr int NQ = M::NQ, NX = 2 * NQ, NU = NQ, KS = NX + NU;
+    if (bf.ctrl->done) return;
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    const int k = g % N, b = g / N;
+    if (b >= B) return;
+    const int traj = KS * N - NU;
+    const float* xu = bf.xu + (size_t)b * traj + (size_t)k * KS;
+    const size_t bk = (size_t)b * N + k;
+    if (k == N - 1) {
+        float c0[NX];
+        const float* x0 = bf.xu + (size_t)b * traj;
+#pragma unroll
+        for (int i = 0; i < NX; i++) c0[i] = x0[i] - bf.x_s[(size_t)b * NX + i];
+        store_vec<NX, NX>(bf.c + (size_t)b * N * NX, c0);
+        return;
+    }
+    float x[KS + NX], fe[6];
+#pragma unroll
+    for (int i = 0; i < KS + NX; i++) x[i] = xu[i];
+#pragma unroll
+    for (int i = 0; i < 6; i++) fe[i] = bf.f_ext[6 * b + i];
+    const float* ref = bf.ref + (size_t)b * 6 * N + 6 * k;
+
+    RBD<M> d;
+    d.set_q(x);
+    {
+        float qdd[NQ], Dq[NQ][NQ], Dd[NQ][NQ], c[NX];
+        typename RBD<M>::MinvT Mi;
+        d.forward_dynamics_grad(x + NQ, x + NX, fe, qdd, Dq, Dd, Mi);
+#pragma unroll
+        for (int i = 0; i < NQ; i++) {
+            const float qdn = x[NQ + i] + dt * qdd[i];
+            const float qn = (float)((double)(x[i] + dt * x[NQ + i]) + 0.5 * (double)qdd[i] * (double)dt * (double)dt);
+            c[i] = x[KS + i] - qn;
+            c[NQ + i] = x[KS + NQ + i] - qdn;
+        }
+        store_vec<NX, NX>(bf.c + (bk + 1) * NX, c);
+        float Dm[3 * NQ * NQ];
+#pragma unroll
+        for (int J = 0; J < NQ; J++)
+#pragma unroll
+            for (int r = 0; r < NQ; r++) {
+                Dm[J * NQ + r] = Dq[J][r];
+                Dm[NQ * NQ + J * NQ + r] = Dd[J][r];
+                Dm[2 * NQ * NQ + J * NQ + r] = Mi.sym(r, J);
+            }
+        store_vec<3 * NQ * NQ, 3 * NQ * NQ>(bf.D + bk * 3 * NQ * NQ, Dm);
+    }
+    {
+        float Qq[NQ * NQ], Qd[NQ], qv[NX], Rd[NU], rv[NU];
+        cost_blocks<M>(d, cw, x, x + NX, ref, Qq, Qd, qv, Rd, rv);
+        store_vec<NQ * NQ, NQ * NQ>(bf.Qq + bk * NQ * NQ, Qq);
+        store_vec<NQ, NQ>(bf.Qd + bk * NQ, Qd);
+        store_vec<NX, NX>(bf.q + bk * NX, qv);
+        store_vec<NU, NU>(bf.Rd + bk * NU, Rd);
+        store_vec<NU, NU>(bf.r + bk * NU, rv);
+        if (k == N - 2) {
+            cost_blocks<M>(d, cw, x, x + NX, ref + 6, Qq, Qd, qv, nullptr, nullptr);
+            store_vec<NQ * NQ, NQ * NQ>(bf.Qq + (bk + 1) * NQ * NQ, Qq);
+            store_vec<NQ, NQ>(bf.Qd + (bk + 1) * NQ, Qd);
+            store_vec<NX, NX>(bf.q + (bk + 1) * NX, qv);
+        }
+    }
+}
+
+// =========================================================================================================================
+// Schur complement formation (schur_linsys.cuh:14-211), one lane per (b,k).
+// =========================================================================================================================
+// Gauss-Jordan inverse without pivoting, the arithmetic of block::invertMatrix (linalg.cuh:364-519) on [V | I]:
+//   THREE = true : a / p * row   (2-/3-matrix overloads, used for Q_k, Q_{k+1}, R_k)
+//   THREE = false: a * (1/p) * row (1-matrix overload, used for theta_k and Q_0)
+// V (col-major n x n) is destroyed; W returns the inverse.
+template<int n, bool THREE> GATO_DEV void gj_inverse(float* V, float* W)
+{
+#pragma unroll
+    for (int i = 0; i < n * n; i++) W[i] = ((i / n) == (i % n)) ? 1.f : 0.f;
+#pragma unroll
+    for (int p = 0; p < n; p++) {
+        // augmented column index j in [p, p+n]: j < n -> V[:, j], else W[:, j-n]
+        float colv[n], rowv[n + 1];
+#pragma unroll
+        for (int i = 0; i < n; i++) colv[i] = V[p * n + i];
+#pragma unroll
+        for (int j = 0; j <= n; j++) {
+            const int cj = p + j;
+            rowv[j] = (cj < n) ? V[cj * n + p] : W[(cj - n) * n + p];
+        }
+        const float pv = colv[p];
+        const float pvInv = 1.0f / pv;
+#pragma unroll
+        for (int j = 0; j <= n; j++) {
+            const int cj = p + j;
+#pragma unroll
+            for (int r = 0; r < n; r++) {
+                float& x = (cj < n) ? V[cj * n + r] : W[(cj - n) * n + r];
+                if constexpr (THREE) {
+                    if (r == p) x = x / pv; else x -= colv[r] / pv * rowv[j];
+                } else {
+                    if (r == p) x *= pvInv; else x -= colv[r] * pvInv * rowv[j];
+                }
+            }
+        }
+    }
+}
+
+template<class M>
+__global__ __launch_bounds__(64) void schur_kernel(Buffers bf, int N, int B, float dt)
+{
+    constexpr int NQ = M::NQ, NX = 2 * NQ, NU = NQ, BR = 3 * NX, BROW = 3 * NX * NX;
+    if (bf.ctrl->done) return;
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    const int k = g % N, b = g / N;
+    if (b >= B) return;
+    const size_t bk = (size_t)b * N + k;
+    const float rho = bf.rho[b];
+    float* S = bf.S + (size_t)b * N * BROW;
+    float* P = bf.Pinv + (size_t)b * N * BROW;
+    float* gam = bf.gamma + (size_t)b * (N + 2) * NX;
+
+    if (k == N - 1) {
+        // the Q_0 row (schur_linsys.cuh:166-210): P^-1 row 0 = -(Q_0 + rho I_q), S row 0 = -(Q_0 + rho I_q)^-1, gamma_0 = c_0 - Q_0^-1 q_0
+        const size_t b0 = (size_t)b * N;
+        float Qq[NQ * NQ], Qi[NQ * NQ], Qd[NQ], q0[NX], c0[NX];
+        load_vec<NQ * NQ, NQ * NQ>(Qq, bf.Qq + b0 * NQ * NQ);
+        load_vec<NQ, NQ>(Qd, bf.Qd + b0 * NQ);
+        load_vec<NX, NX>(q0, bf.q + b0 * NX);
+        load_vec<NX, NX>(c0, bf.c + b0 * NX);
+#pragma unroll
+        for (int i = 0; i < NQ; i++) Qq[i * NQ + i] += rho;
+#pragma unroll
+        for (int y = 0; y < NX; y++) {
+            float row[NX];
+#pragma unroll
+            for (int x = 0; x < NX; x++) {
+                float v = 0.f;
+                if (y < NQ && x < NQ) v = -Qq[x * NQ + y];
+                else if (x == y) v = -Qd[y - NQ];
+                row[x] = v;
+            }
+            store_vec<NX, NX>(P + y * BR + NX, row);
+        }
+        gj_inverse<NQ, false>(Qq, Qi);
+        float di[NQ];
+#pragma unroll
+        for (int i = 0; i < NQ; i++) di[i] = 1.0f * (1.0f / Qd[i]);
+#pragma unroll
+        for (int y = 0; y < NX; y++) {
+            float row[NX];
+#pragma unroll
+            for (int x = 0; x < NX; x++) {
+                float v = 0.f;
+                if (y < NQ && x < NQ) v = -Qi[x * NQ + y];
+                else if (x == y) v = -di[y - NQ];
+                row[x] = v;
+            }
+            store_vec<NX, NX>(S + y * BR + NX, row);
+        }
+        float g0[NX];
+#pragma unroll
+        for (int y = 0; y < NX; y++) {
+            float s = 0.f;
+            if (y < NQ) {
+#pragma unroll
+                for (int j = 0; j < NQ; j++) s += Qi[j * NQ + y] * q0[j];
+            } else {
+                s = di[y - NQ] * q0[y];
+            }
+            g0[y] = c0[y] + (-s);
+        }
+        store_vec<NX, NX>(gam + NX, g0);
+        return;
+    }
+
+    // ---- k <= N-2
+    float Qi[NQ * NQ], Qi1[NQ * NQ], di[NQ], di1[NQ], ri[NU];
+    {
+        float Qq[NQ * NQ], Qd[NQ];
+        load_vec<NQ * NQ, NQ * NQ>(Qq, bf.Qq + bk * NQ * NQ);
+        load_vec<NQ, NQ>(Qd, bf.Qd + bk * NQ);
+#pragma unroll
+        for (int i = 0; i < NQ; i++) Qq[i * NQ + i] += rho;
+        gj_inverse<NQ, true>(Qq, Qi);
+#pragma unroll
+        for (int i = 0; i < NQ; i++) di[i] = 1.0f / Qd[i];
+        load_vec<NQ * NQ, NQ * NQ>(Qq, bf.Qq + (bk + 1) * NQ * NQ);
+        load_vec<NQ, NQ>(Qd, bf.Qd + (bk + 1) * NQ);
+#pragma unroll
+        for (int i = 0; i < NQ; i++) Qq[i * NQ + i] += rho;
+        gj_inverse<NQ, true>(Qq, Qi1);
+#pragma unroll
+        for (int i = 0; i < NQ; i++) di1[i] = 1.0f / Qd[i];
+        float Rd[NU];
+        load_vec<NU, NU>(Rd, bf.Rd + bk * NU);
+#pragma unroll
+        for (int i = 0; i < NU; i++) ri[i] = 1.0f / Rd[i];
+    }
+    store_vec<NQ * NQ, NQ * NQ>(bf.Qqi + bk * NQ * NQ, Qi);
+    store_vec<NQ, NQ>(bf.Qdi + bk * NQ, di);
+    store_vec<NU, NU>(bf.Rdi + bk * NU, ri);
+    if (k == N - 2) {
+        store_vec<NQ * NQ, NQ * NQ>(bf.Qqi + (bk + 1) * NQ * NQ, Qi1);
+        store_vec<NQ, NQ>(bf.Qdi + (bk + 1) * NQ, di1);
+    }
+
+    float Dm[3 * NQ * NQ];
+    load_vec<3 * NQ * NQ, 3 * NQ * NQ>(Dm, bf.D + bk * 3 * NQ * NQ);
+    const float h2 = half_dt_sq(dt);
+    // A (row-major here: Ar[r][c]) and B reconstructed from D
+    float phi[NX][NX];  // phi = A Qinv, [row][col]
+    float theta[NX][NX];
+    {
+        float A[NX][NX], Bm[NX][NU];
+#pragma unroll
+        for (int r = 0; r < NX; r++) {
+#pragma unroll
+            for (int c = 0; c < NX; c++) A[r][c] = A_elem<NQ>(Dm, r, c, dt, h2);
+#pragma unroll
+            for (int c = 0; c < NU; c++) Bm[r][c] = B_elem<NQ>(Dm, r, c, dt, h2);
+        }
+#pragma unroll
+        for (int r = 0; r < NX; r++) {
+#pragma unroll
+            for (int c = 0; c < NQ; c++) {
+                float s = 0.f;
+#pragma unroll
+                for (int j = 0; j < NQ; j++) s += A[r][j] * Qi[c * NQ + j];
+                phi[r][c] = s;
+                phi[r][NQ + c] = A[r][NQ + c] * di[c];
+            }
+        }
+        // theta = Qinv_{k+1} + phi A^T + (B Rinv) B^T
+#pragma unroll
+        for (int y = 0; y < NX; y++)
+#pragma unroll
+            for (int x = 0; x < NX; x++) {
+                float s = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int j = 0; j < NX; j++) s += phi[y][j] * A[x][j];
+#pragma unroll
+                for (int j = 0; j < NU; j++) s2 += (Bm[y][j] * ri[j]) * Bm[x][j];
+                float t = 0.f;
+                if (y < NQ && x < NQ) t = Qi1[x * NQ + y];
+                else if (x == y) t = di1[y - NQ];
+                t += s;
+                t += s2;
+                theta[y][x] = t;
+            }
+        // gamma_{k+1} = c_{k+1} - Qinv_{k+1} q_{k+1} + phi q_k + B Rinv r_k
+        float qk[NX], qk1[NX], rk[NU], ck1[NX], gg[NX];
+        load_vec<NX, NX>(qk, bf.q + bk * NX);
+        load_vec<NX, NX>(qk1, bf.q + (bk + 1) * NX);
+        load_vec<NU, NU>(rk, bf.r + bk * NU);
+        load_vec<NX, NX>(ck1, bf.c + (bk + 1) * NX);
+#pragma unroll
+        for (int y = 0; y < NX; y++) {
+            float g1 = -1.0f * ck1[y];
+            float s = 0.f;
+            if (y < NQ) {
+#pragma unroll
+                for (int j = 0; j < NQ; j++) s += Qi1[j * NQ + y] * qk1[j];
+            } else {
+                s = di1[y - NQ] * qk1[y];
+            }
+            g1 += s;
+            s = 0.f;
+#pragma unroll
+            for (int j = 0; j < NX; j++) s += phi[y][j] * qk[j];
+            g1 += -s;
+            s = 0.f;
+#pragma unroll
+            for (int j = 0; j < NU; j++) s += (Bm[y][j] * ri[j]) * rk[j];
+            g1 += -s;
+            gg[y] = -1.0f * g1;
+        }
+        store_vec<NX, NX>(gam + (size_t)(k + 2) * NX, gg);
+    }
+    // S: row k right = phi^T, row k+1 left = phi, row k+1 main = -theta
+    {
+        float* Sk = S + (size_t)k * BROW;
+        float* Sk1 = S + (size_t)(k + 1) * BROW;
+#pragma unroll
+        for (int y = 0; y < NX; y++) {
+            float row[2 * NX], rt[NX];
+#pragma unroll
+            for (int x = 0; x < NX; x++) {
+                row[x] = phi[y][x];
+                row[NX + x] = -theta[y][x];
+                rt[x] = phi[x][y];
+            }
+            store_vec<2 * NX, NX>(Sk1 + y * BR, row);
+            store_vec<NX, NX>(Sk + y * BR + 2 * NX, rt);
+        }
+    }
+    // P^-1 main diagonal block of row k+1 = -(theta + rho I_q)^-1
+    {
+        float V[NX * NX], W[NX * NX];
+#pragma unroll
+        for (int y = 0; y < NX; y++)
+#pragma unroll
+            for (int x = 0; x < NX; x++) V[x * NX + y] = theta[y][x];
+#pragma unroll
+        for (int i = 0; i < NQ; i++) V[i * NX + i] += rho;
+        gj_inverse<NX, false>(V, W);
+        float* Pk1 = P + (size_t)(k + 1) * BROW;
+#pragma unroll
+        for (int y = 0; y < NX; y++) {
+            float row[NX];
+#pragma unroll
+            for (int x = 0; x < NX; x++) row[x] = -W[x * NX + y];
+            store_vec<NX, NX>(Pk1 + y * BR + NX, row);
+        }
+    }
+}
+
+// stair preconditioner off-diagonals (formSchurSystemBatchedKernel2, schur_linsys.cuh:213-260): for k <= N-2
+//   res = Pm_{k+1} (phi_k Pm_k);  P^-1 row k+1 left = -res, row k right = -res^T   (Pm = the STORED, sign-carrying diagonals)
+template<class M>
+__global__ __launch_bounds__(64) void schur2_kernel(Buffers bf, int N, int B)
+{
+    constexpr int NQ = M::NQ, NX = 2 * NQ, BR = 3 * NX, BROW = 3 * NX * NX;
+    if (bf.ctrl->done) return;
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    const int k = g % N, b = g / N;
+    if (b >= B || k >= N - 1) return;
+    const float* S = bf.S + (size_t)b * N * BROW;
+    float* P = bf.Pinv + (size_t)b * N * BROW;
+    const float* Pk = P + (size_t)k * BROW;
+    float* Pk1 = P + (size_t)(k + 1) * BROW;
+    const float* Sk1 = S + (size_t)(k + 1) * BROW;
+    float scr[NX][NX];  // phi_k Pm_k
+    {
+        float tkm1[NX][NX];
+#pragma unroll
+        for (int y = 0; y < NX; y++) load_vec<NX, NX>(tkm1[y], Pk + y * BR + NX);
+#pragma unroll
+        for (int y = 0; y < NX; y++) {
+            float ph[NX];
+            load_vec<NX, NX>(ph, Sk1 + y * BR);
+#pragma unroll
+            for (int x = 0; x < NX; x++) {
+                float s = 0.f;
+#pragma unroll
+                for (int j = 0; j < NX; j++) s += ph[j] * tkm1[j][x];
+                scr[y][x] = s;
+            }
+        }
+    }
+    float* Pkw = P + (size_t)k * BROW;
+#pragma unroll
+    for (int y = 0; y < NX; y++) {
+        float tk[NX], res[NX];
+        load_vec<NX, NX>(tk, Pk1 + y * BR + NX);
+#pragma unroll
+        for (int x = 0; x < NX; x++) {
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < NX; j++) s += tk[j] * scr[j][x];
+            res[x] = -s;
+        }
+        store_vec<NX, NX>(Pk1 + y * BR, res);  // left of row k+1, row y
+#pragma unroll
+        for (int x = 0; x < NX; x++) Pkw[x * BR + 2 * NX + y] = res[x];  // right of row k: (row x, col y) = -res[y][x]
+    }
+}
+
+// =========================================================================================================================
+// PCG on the block-tridiagonal Schur system S lambda = gamma, preconditioner P^-1 (pcg.cuh:14-148).
+// One workgroup per trajectory; thread t owns rows t, t + T (RPT <= 2) with their S / P^-1 rows in registers.
+// LDS: two padded vectors of (N+2) nx floats + reduction partials.
+// =========================================================================================================================
+template<int NXT> GATO_DEV float row_dot(const float* __restrict__ row, const float* __restrict__ win)
+{
+    // win: LDS window of 3 nx floats starting at the left-neighbour block (16-byte aligned when nx % 4 == 0)
+    float s = 0.f;
+    if constexpr ((3 * NXT) % 4 == 0 && NXT % 4 == 0) {
+#pragma unroll
+        for (int c = 0; c < 3 * NXT / 4; c++) {
+            const float4 v = reinterpret_cast<const float4*>(win)[c];
+            s += row[4 * c] * v.x;
+            s += row[4 * c + 1] * v.y;
+            s += row[4 * c + 2] * v.z;
+            s += row[4 * c + 3] * v.w;
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < 3 * NXT / 2; c++) {
+            const float2 v = reinterpret_cast<const float2*>(win)[c];
+            s += row[2 * c] * v.x;
+            s += row[2 * c + 1] * v.y;
+        }
+    }
+    return s;
+}
+
+GATO_DEV float block_sum(float v, float* part, int nwaves)
+{
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float s = 0.f;
+    for (int i = 0; i < nwaves; i++) s += part[i];
+    return s;
+}
+
+// RPT rows per thread; STREAM = false keeps the thread's S / P^-1 rows in registers, true re-reads them from global memory
+// (L2 / Infinity Cache) for systems that do not fit one CU's register file (iiwa14 N = 128: 602 KB); MAXT = launch bound.
+template<class M, int RPT, bool STREAM, int MAXT>
+__global__ __launch_bounds__(MAXT) void pcg_kernel(Buffers bf, int N, int B, uint32_t max_iters, int sqp_iter)
+{
+    constexpr int NQ = M::NQ, NX = 2 * NQ, BR = 3 * NX, BROW = 3 * NX * NX;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    if (bf.ctrl->done) return;
+    const int b = blockIdx.x;
+    const int T = blockDim.x, nwaves = T >> 6;
+    const int nrows = N * NX, vecp = (N + 2) * NX;
+    float* va = lds;               // padded vector A (x, then p)
+    float* vb = lds + vecp;        // padded vector B (r)
+    float* partA = vb + vecp;      // [16]
+    float* partB = partA + 16;     // [16]
+    const float abs_tol = 1e-6f;
+    uint32_t iters = 0;
+    const bool skip = bf.converged[b] != 0;  // pcg.cuh:29-32
+
+    if (!skip) {
+        const float eps = bf.pcg_tol[b];
+        const float* S = bf.S + (size_t)b * N * BROW;
+        const float* P = bf.Pinv + (size_t)b * N * BROW;
+        const float* gam = bf.gamma + (size_t)b * vecp;
+        float* lam = bf.lambda + (size_t)b * vecp;
+
+        constexpr int RB = STREAM ? 1 : BR;
+        float Srow[RPT][RB], Prow[RPT][RB], xv[RPT], rv[RPT], pv[RPT], zv[RPT];
+        int row[RPT];
+        bool have[RPT];
+        const float* Sg[RPT];
+        const float* Pg[RPT];
+#pragma unroll
+        for (int u = 0; u < RPT; u++) {
+            row[u] = threadIdx.x + u * T;
+            have[u] = row[u] < nrows;
+            const int rr = have[u] ? row[u] : 0;
+            Sg[u] = S + (size_t)rr * BR;
+            Pg[u] = P + (size_t)rr * BR;
+            if constexpr (!STREAM) {
+                load_vec<BR, NX>(Srow[u], Sg[u]);
+                load_vec<BR, NX>(Prow[u], Pg[u]);
+            }
+            xv[u] = have[u] ? lam[NX + rr] : 0.f;
+        }
+        auto sdot = [&](int u, const float* win) -> float {
+            if constexpr (STREAM) {
+                float tmp[BR];
+                load_vec<BR, NX>(tmp, Sg[u]);
+                return row_dot<NX>(tmp, win);
+            } else {
+                return row_dot<NX>(Srow[u], win);
+            }
+        };
+        auto pdot = [&](int u, const float* win) -> float {
+            if constexpr (STREAM) {
+                float tmp[BR];
+                load_vec<BR, NX>(tmp, Pg[u]);
+                return row_dot<NX>(tmp, win);
+            } else {
+                return row_dot<NX>(Prow[u], win);
+            }
+        };
+        // zero the padding blocks of both vectors
+        for (int i = threadIdx.x; i < NX; i += T) {
+            va[i] = 0.f; vb[i] = 0.f;
+            va[vecp - NX + i] = 0.f; vb[vecp - NX + i] = 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < RPT; u++)
+            if (have[u]) va[NX + row[u]] = xv[u];
+        __syncthreads();
+        // r = gamma - S x
+#pragma unroll
+        for (int u = 0; u < RPT; u++) {
+            if (have[u]) {
+                const int kb = row[u] / NX;
+                rv[u] = gam[NX + row[u]] - sdot(u, va + kb * NX);
+                vb[NX + row[u]] = rv[u];
+            } else {
+                rv[u] = 0.f;
+            }
+        }
+        __syncthreads();
+        float loc = 0.f;
+#pragma unroll
+        for (int u = 0; u < RPT; u++) {
+            if (have[u]) {
+                const int kb = row[u] / NX;
+                zv[u] = pdot(u, vb + kb * NX);
+            } else {
+                zv[u] = 0.f;
+            }
+            pv[u] = zv[u];
+            loc += rv[u] * zv[u];
+        }
+        float rho = block_sum(loc, partA, nwaves);
+        if (!(fabsf(rho) < abs_tol)) {
+            const float rho_init = fabsf(rho);
+            for (uint32_t it = 0; it < max_iters; it++) {
+                iters++;
+#pragma unroll
+                for (int u = 0; u < RPT; u++)
+                    if (have[u]) va[NX + row[u]] = pv[u];
+                __syncthreads();
+                float Ap[RPT];
+                loc = 0.f;
+#pragma unroll
+                for (int u = 0; u < RPT; u++) {
+                    Ap[u] = have[u] ? sdot(u, va + (row[u] / NX) * NX) : 0.f;
+                    loc += pv[u] * Ap[u];
+                }
+                const float pAp = block_sum(loc, partB, nwaves);
+                const float alpha = rho / pAp;
+#pragma unroll
+                for (int u = 0; u < RPT; u++) {
+                    xv[u] += alpha * pv[u];
+                    rv[u] -= alpha * Ap[u];
+                    if (have[u]) vb[NX + row[u]] = rv[u];
+                }
+                __syncthreads();
+                loc = 0.f;
+#pragma unroll
+                for (int u = 0; u < RPT; u++) {
+                    zv[u] = have[u] ? pdot(u, vb + (row[u] / NX) * NX) : 0.f;
+                    loc += rv[u] * zv[u];
+                }
+                const float rho_new = block_sum(loc, partA, nwaves);
+                if (fabsf(rho_new) < (abs_tol + eps * rho_init)) break;
+                const float beta = rho_new / rho;
+                rho = rho_new;
+#pragma unroll
+                for (int u = 0; u < RPT; u++) pv[u] = zv[u] + beta * pv[u];
+            }
+#pragma unroll
+            for (int u = 0; u < RPT; u++)
+                if (have[u]) lam[NX + row[u]] = xv[u];
+        }
+    }
+    if (threadIdx.x == 0) {
+        bf.pcg_iters[b] = iters;
+        bf.st_pcg_iters[(size_t)sqp_iter * B + b] = (int32_t)iters;
+        int conv = skip ? 1 : 0;
+        if (iters == 0) { conv = 1; bf.converged[b] = 1; }  // bsqp.cuh:153-156 (kkt_tol is unused there)
+        if (conv) atomicAdd(&bf.num_solved[sqp_iter], 1u);
+    }
+}
+
+// =========================================================================================================================
+// dz recovery (computeDzBatchedKernel, schur_linsys.cuh:316-431), one lane per (b,k); q, r are overwritten by the KKT residuals
+// =========================================================================================================================
+template<class M>
+__global__ __launch_bounds__(256) void dz_kernel(Buffers bf, int N, int B, float dt, int sqp_iter)
+{
+    constexpr int NQ = M::NQ, NX = 2 * NQ, NU = NQ, KS = NX + NU;
+    if (bf.ctrl->done) return;
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g == 0) bf.ctrl->iters_done = sqp_iter + 1;
+    const int k = g % N, b = g / N;
+    if (b >= B) return;
+    const size_t bk = (size_t)b * N + k;
+    const int traj = KS * N - NU;
+    const float* lam = bf.lambda + (size_t)b * (N + 2) * NX;
+    float* dz = bf.dz + (size_t)b * traj + (size_t)k * KS;
+    const float h2 = half_dt_sq(dt);
+    float lk[NX], lk1[NX], Dm[3 * NQ * NQ];
+    load_vec<NX, NX>(lk, lam + (size_t)(k + 1) * NX);
+    const bool inner = k < N - 1;
+    if (inner) {
+        load_vec<NX, NX>(lk1, lam + (size_t)(k + 2) * NX);
+        load_vec<3 * NQ * NQ, 3 * NQ * NQ>(Dm, bf.D + bk * 3 * NQ * NQ);
+    }
+    // state row
+    {
+        float qk[NX], res[NX], Qi[NQ * NQ], di[NQ], out[NX];
+        load_vec<NX, NX>(qk, bf.q + bk * NX);
+        load_vec<NQ * NQ, NQ * NQ>(Qi, bf.Qqi + bk * NQ * NQ);
+        load_vec<NQ, NQ>(di, bf.Qdi + bk * NQ);
+#pragma unroll
+        for (int x = 0; x < NX; x++) {
+            float s = 0.f;
+            if (inner) {
+#pragma unroll
+                for (int j = 0; j < NX; j++) s += lk1[j] * A_elem<NQ>(Dm, j, x, dt, h2);
+                s = -s;
+            }
+            const float scr = s + lk[x];
+            res[x] = qk[x] - scr;
+        }
+#pragma unroll
+        for (int y = 0; y < NX; y++) {
+            float s = 0.f;
+            if (y < NQ) {
+#pragma unroll
+                for (int j = 0; j < NQ; j++) s += Qi[j * NQ + y] * res[j];
+            } else {
+                s = di[y - NQ] * res[y];
+            }
+            out[y] = -1.0f * s;
+        }
+        if (inner) {
+            store_vec<NX, 2>(dz, out);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NX; i++) dz[i] = out[i];  // last knot: dz + k*KS is only 8-byte aligned in general
+        }
+        store_vec<NX, NX>(bf.q + bk * NX, res);
+    }
+    // control row
+    float* rk = bf.r + bk * NU;
+    if (!inner) {
+#pragma unroll
+        for (int i = 0; i < NU; i++) rk[i] = 0.f;
+        return;
+    }
+    {
+        float rr[NU], ri[NU], su[NU], out[NU];
+        load_vec<NU, NU>(rr, rk);
+        load_vec<NU, NU>(ri, bf.Rdi + bk * NU);
+#pragma unroll
+        for (int x = 0; x < NU; x++) {
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < NX; j++) s += lk1[j] * B_elem<NQ>(Dm, j, x, dt, h2);
+            su[x] = rr[x] - (-s);
+            out[x] = -1.0f * (ri[x] * su[x]);
+        }
+#pragma unroll
+        for (int i = 0; i < NU; i++) dz[NX + i] = out[i];
+        store_vec<NU, NU>(rk, su);
+    }
+}
+
+// =========================================================================================================================
+// line search + trajectory update + rho adaptation (line_search.cuh:13-98): one workgroup per trajectory
+// =========================================================================================================================
+__global__ __launch_bounds__(128) void line_search_kernel(Buffers bf, int traj, int B, int adapt_rho, int sqp_iter, float thresh)
+{
+    if (bf.ctrl->done) return;
+    if ((float)bf.num_solved[sqp_iter] >= thresh) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) bf.ctrl->done = 1;  // every block takes the same branch; later kernels see done
+        return;
+    }
+    const int b = blockIdx.x;
+    float* mer = bf.merit + (size_t)b * NUM_ALPHAS;
+    float best = 1e38f;
+    uint32_t idx = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < NUM_ALPHAS; i++) {
+        const float m = mer[i];
+        if (m < best) { best = m; idx = i; }  // first minimum: ties keep the larger alpha
+    }
+    const float cur = bf.merit_cur[b];
+    const bool success = best < cur;
+    __syncthreads();  // everyone has read merit_cur before thread 0 overwrites it
+    if (threadIdx.x == 0) {
+        if (adapt_rho) {
+            const float dr = bf.drho[b];
+            const float mult = success ? fminf(dr / RHO_FACTOR, 1 / RHO_FACTOR) : fmaxf(dr * RHO_FACTOR, RHO_FACTOR);
+            bf.drho[b] = mult;
+            float r = fmaxf(bf.rho[b] * mult, RHO_MIN);
+            r = fminf(r, RHO_MAX);
+            bf.rho[b] = r;
+        }
+        float step = -1.f;
+        if (success) {
+            step = (float)(1.0 / (double)(1 << idx));
+            bf.merit_cur[b] = best;
+        }
+        bf.step[b] = step;
+        bf.st_step[(size_t)sqp_iter * B + b] = step;
+        bf.st_min_merit[(size_t)sqp_iter * B + b] = success ? best : cur;
+        if (b == 0) bf.ctrl->ls_done = sqp_iter + 1;
+    }
+    if (success) {
+        const float step = (float)(1.0 / (double)(1 << idx));
+        float* x = bf.xu + (size_t)b * traj;
+        const float* dz = bf.dz + (size_t)b * traj;
+        for (int i = threadIdx.x; i < traj; i += blockDim.x) x[i] += step * dz[i];
+    }
+}
+
+// =========================================================================================================================
+// forward simulation of ONE shared (x_k, u_k) under B wrench hypotheses (sim.cuh:14-49): one lane per hypothesis
+// =========================================================================================================================
+template<class M>
+__global__ __launch_bounds__(256) void sim_forward_kernel(float* __restrict__ xkp1, const float* __restrict__ xk, const float* __restrict__ uk,
+                                                          const float* __restrict__ f_ext, int B, float dt)
+{
+    constexpr int NQ = M::NQ, NX = 2 * NQ;
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float x[NX], u[NQ], fe[6], qdd[NQ];
+#pragma unroll
+    for (int i = 0; i < NX; i++) x[i] = xk[i];
+#pragma unroll
+    for (int i = 0; i < NQ; i++) u[i] = uk[i];
+#pragma unroll
+    for (int i = 0; i < 6; i++) fe[i] = f_ext[6 * b + i];
+    RBD<M> d;
+    d.set_q(x);
+    d.forward_dynamics(x + NQ, u, fe, qdd);
+#pragma unroll
+    for (int i = 0; i < NQ; i++) {
+        xkp1[(size_t)b * NX + NQ + i] = x[NQ + i] + dt * qdd[i];
+        xkp1[(size_t)b * NX + i] = (float)((double)(x[i] + dt * x[NQ + i]) + 0.5 * (double)qdd[i] * (double)dt * (double)dt);
+    }
+}
+
+// end-effector positions of a batch of configurations (the facade's ee_pos; the reference uses pinocchio FK, interface.py:212-214)
+template<class M>
+__global__ __launch_bounds__(256) void ee_pos_kernel(float* __restrict__ out, const float* __restrict__ q, int n)
+{
+    constexpr int NQ = M::NQ;
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n) return;
+    float qq[NQ], e[3];
+#pragma unroll
+    for (int i = 0; i < NQ; i++) qq[i] = q[(size_t)g * NQ + i];
+    RBD<M> d;
+    d.set_q(qq);
+    d.ee_pos(e);
+    out[3 * g] = e[0]; out[3 * g + 1] = e[1]; out[3 * g + 2] = e[2];
+}
+
+}  // namespace gato

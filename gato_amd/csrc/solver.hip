@@ -1,0 +1,600 @@
+// solver.hip -- host driver + C ABI (include/gato_abi.h) of the MI355X-native batched SQP solver.
+//
+// Replaces, for the reference's hot path, the host class BSQP<T,B> (gato/bsqp/bsqp.cuh) and what PyBSQP<T,B> does around it
+// (python/bindings.cu).  One solve = a fixed sequence of kernel launches on one HIP stream with NO host round trip: the
+// convergence bookkeeping and the solve_ratio early exit of bsqp.cuh:137-176 run on the device (Ctrl / num_solved).
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/gato_abi.h"
+#include "kernels.hpp"
+
+using namespace gato;
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg)
+{
+    g_err = msg;
+    return code;
+}
+#define HIPCHK(expr)                                                                                                       \
+    do {                                                                                                                   \
+        hipError_t e_ = (expr);                                                                                            \
+        if (e_ != hipSuccess) return fail(GATO_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                \
+    } while (0)
+
+enum Stage { ST_MERIT = 0, ST_KKT, ST_SCHUR, ST_PCG, ST_DZ, ST_LS, ST_COUNT };
+
+struct GatoSolver {
+    int plant, N, B, nq, nx, nu, traj, vecp, brow;
+    int device;
+    GatoParams p;
+    Costs cw;
+    int adapt_rho;
+    uint32_t max_iters_alloc;
+    Buffers bf;
+    float *d_xu_own, *d_xs_own, *d_ref_own, *d_merit_init0, *d_drho_init, *d_rho_init, *d_scratch_B;
+    std::vector<float> h_rho_init, h_drho_init;
+    hipStream_t last_stream;
+    std::vector<void*> allocs;
+    // profiling
+    int profiling;
+    std::vector<hipEvent_t> events;
+    std::vector<int> event_stage;  // stage that ENDS at event i (event 0 = start)
+    double stage_us[ST_COUNT + 1];
+};
+
+template<typename T> static int dalloc(GatoSolver* s, T** p, size_t count, bool zero = true)
+{
+    void* d = nullptr;
+    size_t bytes = (count ? count : 1) * sizeof(T);
+    HIPCHK(hipMalloc(&d, bytes));
+    if (zero) HIPCHK(hipMemset(d, 0, bytes));
+    s->allocs.push_back(d);
+    *p = (T*)d;
+    return GATO_OK;
+}
+
+extern "C" void gato_default_params(GatoParams* p)
+{
+    // BSQP() default constructor, bsqp.cuh:24-27
+    p->dt = 0.01f; p->max_sqp_iters = 5; p->kkt_tol = 0.0001f; p->max_pcg_iters = 100; p->pcg_tol = 1e-5f; p->solve_ratio = 1.0f;
+    p->mu = 10.0f; p->q_cost = 1.0f; p->qd_cost = 1e-3f; p->u_cost = 1e-6f; p->N_cost = 50.0f; p->q_lim_cost = 1e-3f;
+    p->vel_lim_cost = 0.0f; p->ctrl_lim_cost = 0.0f; p->rho = 1e-3f;
+}
+
+extern "C" int gato_dims(int plant, int N, int* nq, int* nx, int* nu, int* traj)
+{
+    int q = plant == GATO_PLANT_INDY7 ? 6 : (plant == GATO_PLANT_IIWA14 ? 7 : 0);
+    if (!q) return fail(GATO_ERR_INVALID, "unknown plant");
+    if (nq) *nq = q;
+    if (nx) *nx = 2 * q;
+    if (nu) *nu = q;
+    if (traj) *traj = 3 * q * N - q;
+    return GATO_OK;
+}
+
+extern "C" int gato_create(int plant, int N, int B, const GatoParams* params, GatoSolver** out)
+{
+    if (!out || !params) return fail(GATO_ERR_INVALID, "null argument");
+    if (plant != GATO_PLANT_INDY7 && plant != GATO_PLANT_IIWA14) return fail(GATO_ERR_INVALID, "unknown plant");
+    if (N < 4 || N > 256 || (N & (N - 1))) return fail(GATO_ERR_INVALID, "knot_points must be a power of two in [4, 256]");
+    if (B < 1) return fail(GATO_ERR_INVALID, "batch must be >= 1");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(GATO_ERR_NO_DEVICE, "no HIP device visible");
+    GatoSolver* s = new GatoSolver();
+    s->plant = plant; s->N = N; s->B = B;
+    gato_dims(plant, N, &s->nq, &s->nx, &s->nu, &s->traj);
+    s->vecp = (N + 2) * s->nx;
+    s->brow = 3 * s->nx * s->nx;
+    s->p = *params;
+    s->cw = Costs{params->q_cost, params->qd_cost, params->u_cost, params->N_cost, params->q_lim_cost, params->vel_lim_cost, params->ctrl_lim_cost};
+    s->adapt_rho = 1;
+    s->profiling = 0;
+    s->last_stream = nullptr;
+    memset(s->stage_us, 0, sizeof(s->stage_us));
+    HIPCHK(hipGetDevice(&s->device));
+    const int nq = s->nq, nx = s->nx, nu = s->nu;
+    const size_t BN = (size_t)B * N;
+    s->max_iters_alloc = params->max_sqp_iters ? params->max_sqp_iters : 1;
+    Buffers& bf = s->bf;
+    memset(&bf, 0, sizeof(bf));
+    int rc;
+#define DA(ptr, n) if ((rc = dalloc(s, &(ptr), (n))) != GATO_OK) { gato_destroy(s); return rc; }
+    DA(bf.lambda, (size_t)B * s->vecp);
+    DA(bf.rho, B); DA(bf.drho, B); DA(bf.mu, B); DA(bf.pcg_tol, B); DA(bf.f_ext, 6 * (size_t)B);
+    DA(bf.D, BN * 3 * nq * nq); DA(bf.Qq, BN * nq * nq); DA(bf.Qd, BN * nq); DA(bf.Rd, BN * nu);
+    DA(bf.q, BN * nx); DA(bf.r, BN * nu); DA(bf.c, BN * nx);
+    DA(bf.Qqi, BN * nq * nq); DA(bf.Qdi, BN * nq); DA(bf.Rdi, BN * nu);
+    DA(bf.S, BN * s->brow); DA(bf.Pinv, BN * s->brow); DA(bf.gamma, (size_t)B * s->vecp);  // zero padding blocks are relied upon
+    DA(bf.dz, (size_t)B * s->traj);
+    DA(bf.merit, (size_t)B * NUM_ALPHAS); DA(bf.merit_cur, B); DA(bf.step, B);
+    DA(bf.converged, B); DA(bf.pcg_iters, B);
+    DA(bf.st_pcg_iters, (size_t)s->max_iters_alloc * B); DA(bf.st_min_merit, (size_t)s->max_iters_alloc * B);
+    DA(bf.st_step, (size_t)s->max_iters_alloc * B);
+    DA(bf.ctrl, 1); DA(bf.num_solved, s->max_iters_alloc);
+    DA(s->d_xu_own, (size_t)B * s->traj); DA(s->d_xs_own, (size_t)B * nx); DA(s->d_ref_own, (size_t)B * 6 * N);
+    DA(s->d_merit_init0, B); DA(s->d_drho_init, B); DA(s->d_rho_init, B); DA(s->d_scratch_B, (size_t)B * nx);
+#undef DA
+    // per-trajectory defaults (bsqp.cuh:48-58)
+    s->h_rho_init.assign(B, params->rho);
+    s->h_drho_init.assign(B, 1.0f);
+    std::vector<float> mu(B, params->mu), tol(B, params->pcg_tol);
+    HIPCHK(hipMemcpy(bf.rho, s->h_rho_init.data(), B * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(bf.drho, s->h_drho_init.data(), B * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(s->d_drho_init, s->h_drho_init.data(), B * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(s->d_rho_init, s->h_rho_init.data(), B * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(bf.mu, mu.data(), B * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(bf.pcg_tol, tol.data(), B * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(hipDeviceSynchronize());
+    *out = s;
+    return GATO_OK;
+}
+
+extern "C" int gato_destroy(GatoSolver* s)
+{
+    if (!s) return GATO_OK;
+    for (void* p : s->allocs) (void)hipFree(p);
+    for (hipEvent_t e : s->events) (void)hipEventDestroy(e);
+    delete s;
+    return GATO_OK;
+}
+
+// ---- launches ---------------------------------------------------------------------------------------------------------
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+template<class M> static void launch_merit(GatoSolver* s, hipStream_t st, int na, float dt, int use_dz, int sqp_iter, float* out)
+{
+    const float thresh = (float)s->B * s->p.solve_ratio;
+    const long n = (long)s->B * na * s->N;
+    if (na == 1)
+        hipLaunchKernelGGL((merit_kernel<M, 1>), dim3(cdiv(n, 256)), dim3(256), 0, st, s->bf, s->cw, s->N, s->B, dt, use_dz, sqp_iter, thresh, out);
+    else
+        hipLaunchKernelGGL((merit_kernel<M, NUM_ALPHAS>), dim3(cdiv(n, 256)), dim3(256), 0, st, s->bf, s->cw, s->N, s->B, dt, use_dz, sqp_iter,
+                           thresh, out);
+}
+template<class M> static void launch_kkt(GatoSolver* s, hipStream_t st, float dt)
+{
+    hipLaunchKernelGGL((kkt_kernel<M>), dim3(cdiv((long)s->B * s->N, 64)), dim3(64), 0, st, s->bf, s->cw, s->N, s->B, dt);
+}
+template<class M> static void launch_schur(GatoSolver* s, hipStream_t st, float dt)
+{
+    hipLaunchKernelGGL((schur_kernel<M>), dim3(cdiv((long)s->B * s->N, 64)), dim3(64), 0, st, s->bf, s->N, s->B, dt);
+    hipLaunchKernelGGL((schur2_kernel<M>), dim3(cdiv((long)s->B * s->N, 64)), dim3(64), 0, st, s->bf, s->N, s->B);
+}
+template<class M> static void launch_pcg(GatoSolver* s, hipStream_t st, int sqp_iter)
+{
+    const int rows = s->N * s->nx;
+    const size_t lds = (size_t)(2 * s->vecp + 32) * sizeof(float);
+    const int T1 = ((rows + 63) / 64) * 64;
+    if (T1 <= 512) {
+        hipLaunchKernelGGL((pcg_kernel<M, 1, false, 512>), dim3(s->B), dim3(T1), lds, st, s->bf, s->N, s->B, s->p.max_pcg_iters, sqp_iter);
+    } else if (T1 <= 1024) {
+        hipLaunchKernelGGL((pcg_kernel<M, 1, false, 1024>), dim3(s->B), dim3(T1), lds, st, s->bf, s->N, s->B, s->p.max_pcg_iters, sqp_iter);
+    } else {
+        const int T2 = (((rows + 1) / 2 + 63) / 64) * 64;
+        if (T2 <= 768) {
+            hipLaunchKernelGGL((pcg_kernel<M, 2, false, 768>), dim3(s->B), dim3(T2), lds, st, s->bf, s->N, s->B, s->p.max_pcg_iters, sqp_iter);
+        } else if (T2 <= 1024) {
+            hipLaunchKernelGGL((pcg_kernel<M, 2, true, 1024>), dim3(s->B), dim3(T2), lds, st, s->bf, s->N, s->B, s->p.max_pcg_iters, sqp_iter);
+        } else {
+            const int T4 = (((rows + 3) / 4 + 63) / 64) * 64;  // N = 256
+            hipLaunchKernelGGL((pcg_kernel<M, 4, true, 1024>), dim3(s->B), dim3(T4), lds, st, s->bf, s->N, s->B, s->p.max_pcg_iters, sqp_iter);
+        }
+    }
+}
+template<class M> static void launch_dz(GatoSolver* s, hipStream_t st, float dt, int sqp_iter)
+{
+    hipLaunchKernelGGL((dz_kernel<M>), dim3(cdiv((long)s->B * s->N, 256)), dim3(256), 0, st, s->bf, s->N, s->B, dt, sqp_iter);
+}
+static void launch_ls(GatoSolver* s, hipStream_t st, int sqp_iter)
+{
+    const float thresh = (float)s->B * s->p.solve_ratio;
+    hipLaunchKernelGGL(line_search_kernel, dim3(s->B), dim3(128), 0, st, s->bf, s->traj, s->B, s->adapt_rho, sqp_iter, thresh);
+}
+
+static void mark(GatoSolver* s, hipStream_t st, int stage, size_t& ei)
+{
+    if (!s->profiling) return;
+    if (ei >= s->events.size()) {
+        hipEvent_t e;
+        (void)hipEventCreate(&e);
+        s->events.push_back(e);
+        s->event_stage.push_back(stage);
+    }
+    s->event_stage[ei] = stage;
+    (void)hipEventRecord(s->events[ei], st);
+    ei++;
+}
+
+template<class M> static int solve_impl(GatoSolver* s, float* d_xu, float dt, const float* d_xs, const float* d_ref, hipStream_t st)
+{
+    Buffers& bf = s->bf;
+    const int B = s->B;
+    bf.xu = d_xu; bf.x_s = d_xs; bf.ref = d_ref;
+    s->last_stream = st;
+    size_t ei = 0;
+    // bsqp.cuh:112-114 (+ the device-side loop control)
+    HIPCHK(hipMemsetAsync(bf.dz, 0, (size_t)B * s->traj * sizeof(float), st));
+    HIPCHK(hipMemsetAsync(bf.pcg_iters, 0, B * sizeof(uint32_t), st));
+    HIPCHK(hipMemsetAsync(bf.converged, 0, B * sizeof(int32_t), st));
+    HIPCHK(hipMemsetAsync(bf.ctrl, 0, sizeof(Ctrl), st));
+    HIPCHK(hipMemsetAsync(bf.num_solved, 0, s->max_iters_alloc * sizeof(uint32_t), st));
+    mark(s, st, -1, ei);
+    launch_merit<M>(s, st, 1, dt, 0, -1, bf.merit_cur);  // bsqp.cuh:116-118
+    HIPCHK(hipMemcpyAsync(s->d_merit_init0, bf.merit_cur, B * sizeof(float), hipMemcpyDeviceToDevice, st));
+    mark(s, st, ST_MERIT, ei);
+    const uint32_t iters = s->p.max_sqp_iters <= s->max_iters_alloc ? s->p.max_sqp_iters : s->max_iters_alloc;
+    for (uint32_t it = 0; it < iters; it++) {
+        launch_kkt<M>(s, st, dt);
+        mark(s, st, ST_KKT, ei);
+        launch_schur<M>(s, st, dt);
+        mark(s, st, ST_SCHUR, ei);
+        launch_pcg<M>(s, st, (int)it);
+        mark(s, st, ST_PCG, ei);
+        launch_dz<M>(s, st, dt, (int)it);
+        mark(s, st, ST_DZ, ei);
+        launch_merit<M>(s, st, NUM_ALPHAS, dt, 1, (int)it, bf.merit);
+        mark(s, st, ST_MERIT, ei);
+        launch_ls(s, st, (int)it);
+        mark(s, st, ST_LS, ei);
+    }
+    launch_merit<M>(s, st, 1, dt, 0, -1, bf.merit_cur);  // final merit of the returned xu (bsqp.cuh:180-182)
+    mark(s, st, ST_MERIT, ei);
+    HIPCHK(hipMemcpyAsync(bf.drho, s->d_drho_init, B * sizeof(float), hipMemcpyDeviceToDevice, st));  // bsqp.cuh:189; rho is NOT reset
+    HIPCHK(hipGetLastError());
+    return GATO_OK;
+}
+
+static int solve_dispatch(GatoSolver* s, float* d_xu, float dt, const float* d_xs, const float* d_ref, hipStream_t st)
+{
+    return s->plant == GATO_PLANT_INDY7 ? solve_impl<Indy7>(s, d_xu, dt, d_xs, d_ref, st) : solve_impl<Iiwa14>(s, d_xu, dt, d_xs, d_ref, st);
+}
+
+static void collect_profile(GatoSolver* s)
+{
+    if (!s->profiling || s->events.size() < 2) return;
+    memset(s->stage_us, 0, sizeof(s->stage_us));
+    for (size_t i = 1; i < s->events.size(); i++) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, s->events[i - 1], s->events[i]) == hipSuccess && s->event_stage[i] >= 0) s->stage_us[s->event_stage[i]] += ms * 1e3;
+    }
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, s->events.front(), s->events.back()) == hipSuccess) s->stage_us[ST_COUNT] = ms * 1e3;
+}
+
+extern "C" int gato_solve_device(GatoSolver* s, float* d_xu, float dt, const float* d_xs, const float* d_ref, void* stream)
+{
+    if (!s || !d_xu || !d_xs || !d_ref) return fail(GATO_ERR_INVALID, "null argument");
+    return solve_dispatch(s, d_xu, dt, d_xs, d_ref, (hipStream_t)stream);
+}
+
+extern "C" int gato_solve(GatoSolver* s, float* xu, float dt, const float* x_s, const float* ref, double* sqp_time_us)
+{
+    if (!s || !xu || !x_s || !ref) return fail(GATO_ERR_INVALID, "null argument");
+    const size_t nxu = (size_t)s->B * s->traj * sizeof(float);
+    HIPCHK(hipMemcpy(s->d_xu_own, xu, nxu, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(s->d_xs_own, x_s, (size_t)s->B * s->nx * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(s->d_ref_own, ref, (size_t)s->B * 6 * s->N * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(hipDeviceSynchronize());
+    auto t0 = std::chrono::high_resolution_clock::now();
+    int rc = solve_dispatch(s, s->d_xu_own, dt, s->d_xs_own, s->d_ref_own, nullptr);
+    if (rc != GATO_OK) return rc;
+    HIPCHK(hipDeviceSynchronize());
+    auto t1 = std::chrono::high_resolution_clock::now();
+    if (sqp_time_us) *sqp_time_us = std::chrono::duration<double, std::micro>(t1 - t0).count();
+    collect_profile(s);
+    HIPCHK(hipMemcpy(xu, s->d_xu_own, nxu, hipMemcpyDeviceToHost));
+    return GATO_OK;
+}
+
+// ---- statistics -------------------------------------------------------------------------------------------------------
+static int sync_last(GatoSolver* s)
+{
+    HIPCHK(hipStreamSynchronize(s->last_stream));
+    return GATO_OK;
+}
+extern "C" int gato_get_counts(GatoSolver* s, uint32_t* iters_done, uint32_t* ls)
+{
+    if (!s) return fail(GATO_ERR_INVALID, "null solver");
+    int rc = sync_last(s);
+    if (rc) return rc;
+    Ctrl c;
+    HIPCHK(hipMemcpy(&c, s->bf.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost));
+    if (iters_done) *iters_done = c.iters_done;
+    if (ls) *ls = c.ls_done;
+    return GATO_OK;
+}
+extern "C" int gato_get_sqp_iters(GatoSolver* s, int32_t* out)
+{
+    uint32_t it = 0;
+    int rc = gato_get_counts(s, &it, nullptr);
+    if (rc) return rc;
+    for (int b = 0; b < s->B; b++) out[b] = (int32_t)it;  // every trajectory counts every executed iteration (bsqp.cuh:153-162)
+    return GATO_OK;
+}
+extern "C" int gato_get_kkt_converged(GatoSolver* s, int32_t* out)
+{
+    if (!s || !out) return fail(GATO_ERR_INVALID, "null argument");
+    int rc = sync_last(s);
+    if (rc) return rc;
+    HIPCHK(hipMemcpy(out, s->bf.converged, s->B * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return GATO_OK;
+}
+extern "C" int gato_get_final_merit(GatoSolver* s, float* out)
+{
+    if (!s || !out) return fail(GATO_ERR_INVALID, "null argument");
+    int rc = sync_last(s);
+    if (rc) return rc;
+    HIPCHK(hipMemcpy(out, s->bf.merit_cur, s->B * sizeof(float), hipMemcpyDeviceToHost));
+    return GATO_OK;
+}
+extern "C" int gato_get_initial_merit(GatoSolver* s, float* out)
+{
+    if (!s || !out) return fail(GATO_ERR_INVALID, "null argument");
+    int rc = sync_last(s);
+    if (rc) return rc;
+    HIPCHK(hipMemcpy(out, s->d_merit_init0, s->B * sizeof(float), hipMemcpyDeviceToHost));
+    return GATO_OK;
+}
+extern "C" int gato_get_pcg_iters(GatoSolver* s, int32_t* out)
+{
+    uint32_t it = 0;
+    int rc = gato_get_counts(s, &it, nullptr);
+    if (rc) return rc;
+    if (it) HIPCHK(hipMemcpy(out, s->bf.st_pcg_iters, (size_t)it * s->B * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return GATO_OK;
+}
+extern "C" int gato_get_ls_min_merit(GatoSolver* s, float* out)
+{
+    uint32_t ls = 0;
+    int rc = gato_get_counts(s, nullptr, &ls);
+    if (rc) return rc;
+    if (ls) HIPCHK(hipMemcpy(out, s->bf.st_min_merit, (size_t)ls * s->B * sizeof(float), hipMemcpyDeviceToHost));
+    return GATO_OK;
+}
+extern "C" int gato_get_ls_step_size(GatoSolver* s, float* out)
+{
+    uint32_t ls = 0;
+    int rc = gato_get_counts(s, nullptr, &ls);
+    if (rc) return rc;
+    if (ls) HIPCHK(hipMemcpy(out, s->bf.st_step, (size_t)ls * s->B * sizeof(float), hipMemcpyDeviceToHost));
+    return GATO_OK;
+}
+
+// ---- setters (bsqp.cuh:63-89) -------------------------------------------------------------------------------------------
+extern "C" int gato_set_f_ext_batch(GatoSolver* s, const float* v)
+{
+    if (!s || !v) return fail(GATO_ERR_INVALID, "null argument");
+    HIPCHK(hipMemcpy(s->bf.f_ext, v, 6 * (size_t)s->B * sizeof(float), hipMemcpyHostToDevice));
+    return GATO_OK;
+}
+extern "C" int gato_set_rho_penalty_batch(GatoSolver* s, const float* v, int as_default)
+{
+    if (!s || !v) return fail(GATO_ERR_INVALID, "null argument");
+    if (as_default) {
+        s->h_rho_init.assign(v, v + s->B);
+        HIPCHK(hipMemcpy(s->d_rho_init, v, s->B * sizeof(float), hipMemcpyHostToDevice));
+    }
+    HIPCHK(hipMemcpy(s->bf.rho, v, s->B * sizeof(float), hipMemcpyHostToDevice));
+    return GATO_OK;
+}
+extern "C" int gato_set_drho_batch(GatoSolver* s, const float* v, int as_default)
+{
+    if (!s || !v) return fail(GATO_ERR_INVALID, "null argument");
+    if (as_default) {
+        s->h_drho_init.assign(v, v + s->B);
+        HIPCHK(hipMemcpy(s->d_drho_init, v, s->B * sizeof(float), hipMemcpyHostToDevice));
+    }
+    HIPCHK(hipMemcpy(s->bf.drho, v, s->B * sizeof(float), hipMemcpyHostToDevice));
+    return GATO_OK;
+}
+extern "C" int gato_set_mu_batch(GatoSolver* s, const float* v)
+{
+    if (!s || !v) return fail(GATO_ERR_INVALID, "null argument");
+    HIPCHK(hipMemcpy(s->bf.mu, v, s->B * sizeof(float), hipMemcpyHostToDevice));
+    return GATO_OK;
+}
+extern "C" int gato_set_pcg_tol_batch(GatoSolver* s, const float* v)
+{
+    if (!s || !v) return fail(GATO_ERR_INVALID, "null argument");
+    HIPCHK(hipMemcpy(s->bf.pcg_tol, v, s->B * sizeof(float), hipMemcpyHostToDevice));
+    return GATO_OK;
+}
+extern "C" int gato_reset_dual(GatoSolver* s)
+{
+    if (!s) return fail(GATO_ERR_INVALID, "null solver");
+    HIPCHK(hipMemset(s->bf.lambda, 0, (size_t)s->B * s->vecp * sizeof(float)));
+    return GATO_OK;
+}
+extern "C" int gato_reset_rho(GatoSolver* s)
+{
+    if (!s) return fail(GATO_ERR_INVALID, "null solver");
+    HIPCHK(hipMemcpy(s->bf.rho, s->h_rho_init.data(), s->B * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(s->bf.drho, s->h_drho_init.data(), s->B * sizeof(float), hipMemcpyHostToDevice));
+    return GATO_OK;
+}
+extern "C" int gato_reset_async(GatoSolver* s, int dual, int rho, void* stream)
+{
+    if (!s) return fail(GATO_ERR_INVALID, "null solver");
+    hipStream_t st = (hipStream_t)stream;
+    if (dual) HIPCHK(hipMemsetAsync(s->bf.lambda, 0, (size_t)s->B * s->vecp * sizeof(float), st));
+    if (rho) {
+        HIPCHK(hipMemcpyAsync(s->bf.rho, s->d_rho_init, s->B * sizeof(float), hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipMemcpyAsync(s->bf.drho, s->d_drho_init, s->B * sizeof(float), hipMemcpyDeviceToDevice, st));
+    }
+    return GATO_OK;
+}
+extern "C" int gato_copy_final_merit_device(GatoSolver* s, float* d_out, void* stream)
+{
+    if (!s || !d_out) return fail(GATO_ERR_INVALID, "null argument");
+    HIPCHK(hipMemcpyAsync(d_out, s->bf.merit_cur, s->B * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return GATO_OK;
+}
+extern "C" int gato_set_rho_adaptation(GatoSolver* s, int enabled)
+{
+    if (!s) return fail(GATO_ERR_INVALID, "null solver");
+    s->adapt_rho = enabled ? 1 : 0;
+    return GATO_OK;
+}
+
+// ---- sim_forward / ee_pos -----------------------------------------------------------------------------------------------
+extern "C" int gato_sim_forward(GatoSolver* s, float* xkp1, const float* xk, const float* uk, float dt)
+{
+    if (!s || !xkp1 || !xk || !uk) return fail(GATO_ERR_INVALID, "null argument");
+    float* d_in = s->d_xs_own;  // reuse: nx + nu floats fit in B*nx
+    HIPCHK(hipMemcpy(d_in, xk, s->nx * sizeof(float), hipMemcpyHostToDevice));
+    float* d_u = nullptr;
+    std::vector<float> tmp(uk, uk + s->nu);
+    HIPCHK(hipMalloc((void**)&d_u, s->nu * sizeof(float)));
+    HIPCHK(hipMemcpy(d_u, tmp.data(), s->nu * sizeof(float), hipMemcpyHostToDevice));
+    if (s->plant == GATO_PLANT_INDY7)
+        hipLaunchKernelGGL((sim_forward_kernel<Indy7>), dim3(cdiv(s->B, 256)), dim3(256), 0, nullptr, s->d_scratch_B, d_in, d_u, s->bf.f_ext, s->B, dt);
+    else
+        hipLaunchKernelGGL((sim_forward_kernel<Iiwa14>), dim3(cdiv(s->B, 256)), dim3(256), 0, nullptr, s->d_scratch_B, d_in, d_u, s->bf.f_ext, s->B, dt);
+    hipError_t e = hipDeviceSynchronize();
+    (void)hipFree(d_u);
+    if (e != hipSuccess) return fail(GATO_ERR_HIP, hipGetErrorString(e));
+    HIPCHK(hipMemcpy(xkp1, s->d_scratch_B, (size_t)s->B * s->nx * sizeof(float), hipMemcpyDeviceToHost));
+    return GATO_OK;
+}
+
+extern "C" int gato_ee_pos(GatoSolver* s, const float* q, int n, float* out)
+{
+    if (!s || !q || !out || n < 0) return fail(GATO_ERR_INVALID, "bad argument");
+    if (n == 0) return GATO_OK;
+    float *d_q = nullptr, *d_o = nullptr;
+    HIPCHK(hipMalloc((void**)&d_q, (size_t)n * s->nq * sizeof(float)));
+    if (hipMalloc((void**)&d_o, (size_t)n * 3 * sizeof(float)) != hipSuccess) { (void)hipFree(d_q); return fail(GATO_ERR_HIP, "hipMalloc"); }
+    hipError_t e = hipMemcpy(d_q, q, (size_t)n * s->nq * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        if (s->plant == GATO_PLANT_INDY7) hipLaunchKernelGGL((ee_pos_kernel<Indy7>), dim3(cdiv(n, 256)), dim3(256), 0, nullptr, d_o, d_q, n);
+        else hipLaunchKernelGGL((ee_pos_kernel<Iiwa14>), dim3(cdiv(n, 256)), dim3(256), 0, nullptr, d_o, d_q, n);
+        e = hipMemcpy(out, d_o, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost);
+    }
+    (void)hipFree(d_q);
+    (void)hipFree(d_o);
+    if (e != hipSuccess) return fail(GATO_ERR_HIP, hipGetErrorString(e));
+    return GATO_OK;
+}
+
+// ---- debug / test access ------------------------------------------------------------------------------------------------
+static float* find_buf(GatoSolver* s, const char* name, uint64_t* len)
+{
+    const size_t BN = (size_t)s->B * s->N;
+    const int nq = s->nq, nx = s->nx, nu = s->nu;
+    struct E { const char* n; float* p; uint64_t l; };
+    const E tab[] = {
+        {"D", s->bf.D, BN * 3 * nq * nq}, {"Qq", s->bf.Qq, BN * nq * nq}, {"Qd", s->bf.Qd, BN * nq}, {"Rd", s->bf.Rd, BN * nu},
+        {"q", s->bf.q, BN * nx}, {"r", s->bf.r, BN * nu}, {"c", s->bf.c, BN * nx}, {"Qqi", s->bf.Qqi, BN * nq * nq}, {"Qdi", s->bf.Qdi, BN * nq},
+        {"Rdi", s->bf.Rdi, BN * nu}, {"S", s->bf.S, BN * s->brow}, {"Pinv", s->bf.Pinv, BN * s->brow},
+        {"gamma", s->bf.gamma, (uint64_t)s->B * s->vecp}, {"lambda", s->bf.lambda, (uint64_t)s->B * s->vecp},
+        {"dz", s->bf.dz, (uint64_t)s->B * s->traj}, {"merit", s->bf.merit, (uint64_t)s->B * NUM_ALPHAS}, {"merit_cur", s->bf.merit_cur, (uint64_t)s->B},
+        {"rho", s->bf.rho, (uint64_t)s->B}, {"drho", s->bf.drho, (uint64_t)s->B}, {"step", s->bf.step, (uint64_t)s->B},
+        {"mu", s->bf.mu, (uint64_t)s->B}, {"pcg_tol", s->bf.pcg_tol, (uint64_t)s->B}, {"f_ext", s->bf.f_ext, (uint64_t)s->B * 6},
+    };
+    for (const E& e : tab)
+        if (!strcmp(e.n, name)) { *len = e.l; return e.p; }
+    return nullptr;
+}
+extern "C" int gato_debug_read(GatoSolver* s, const char* name, float* out, uint64_t count, uint64_t* len)
+{
+    if (!s || !name) return fail(GATO_ERR_INVALID, "null argument");
+    uint64_t l = 0;
+    float* p = find_buf(s, name, &l);
+    if (!p) {
+        if (!strcmp(name, "pcg_iters") || !strcmp(name, "converged")) {  // integer buffers, returned as floats
+            std::vector<int32_t> t(s->B);
+            HIPCHK(hipDeviceSynchronize());
+            HIPCHK(hipMemcpy(t.data(), !strcmp(name, "pcg_iters") ? (void*)s->bf.pcg_iters : (void*)s->bf.converged, s->B * sizeof(int32_t), hipMemcpyDeviceToHost));
+            if (len) *len = s->B;
+            if (out) for (uint64_t i = 0; i < count && i < (uint64_t)s->B; i++) out[i] = (float)t[i];
+            return GATO_OK;
+        }
+        return fail(GATO_ERR_INVALID, std::string("unknown buffer ") + name);
+    }
+    if (len) *len = l;
+    if (!out) return GATO_OK;
+    if (count > l) return fail(GATO_ERR_INVALID, "count exceeds buffer length");
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(out, p, count * sizeof(float), hipMemcpyDeviceToHost));
+    return GATO_OK;
+}
+extern "C" int gato_debug_write(GatoSolver* s, const char* name, const float* in, uint64_t count)
+{
+    if (!s || !name || !in) return fail(GATO_ERR_INVALID, "null argument");
+    uint64_t l = 0;
+    float* p = find_buf(s, name, &l);
+    if (!p) {
+        if (!strcmp(name, "converged")) {
+            std::vector<int32_t> t(s->B, 0);
+            for (uint64_t i = 0; i < count && i < (uint64_t)s->B; i++) t[i] = (int32_t)in[i];
+            HIPCHK(hipMemcpy(s->bf.converged, t.data(), s->B * sizeof(int32_t), hipMemcpyHostToDevice));
+            return GATO_OK;
+        }
+        return fail(GATO_ERR_INVALID, std::string("unknown buffer ") + name);
+    }
+    if (count > l) return fail(GATO_ERR_INVALID, "count exceeds buffer length");
+    HIPCHK(hipMemcpy(p, in, count * sizeof(float), hipMemcpyHostToDevice));
+    return GATO_OK;
+}
+
+template<class M> static int stage_impl(GatoSolver* s, int stage, float dt, float* out)
+{
+    Buffers& bf = s->bf;
+    hipStream_t st = nullptr;
+    HIPCHK(hipMemsetAsync(bf.ctrl, 0, sizeof(Ctrl), st));
+    HIPCHK(hipMemsetAsync(bf.num_solved, 0, s->max_iters_alloc * sizeof(uint32_t), st));
+    switch (stage) {
+        case 0: launch_merit<M>(s, st, NUM_ALPHAS, dt, 1, 0, bf.merit); break;
+        case 1: launch_kkt<M>(s, st, dt); break;
+        case 2: launch_schur<M>(s, st, dt); break;
+        case 3: launch_pcg<M>(s, st, 0); break;
+        case 4: launch_dz<M>(s, st, dt, 0); break;
+        case 5: launch_ls(s, st, 0); break;
+        case 6: launch_merit<M>(s, st, 1, dt, 0, -1, bf.merit_cur); break;
+        default: return fail(GATO_ERR_INVALID, "unknown stage");
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    (void)out;
+    return GATO_OK;
+}
+extern "C" int gato_debug_stage(GatoSolver* s, int stage, float* xu, float dt, const float* x_s, const float* ref, float* out)
+{
+    if (!s || !xu || !x_s || !ref) return fail(GATO_ERR_INVALID, "null argument");
+    const size_t nxu = (size_t)s->B * s->traj * sizeof(float);
+    HIPCHK(hipMemcpy(s->d_xu_own, xu, nxu, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(s->d_xs_own, x_s, (size_t)s->B * s->nx * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(s->d_ref_own, ref, (size_t)s->B * 6 * s->N * sizeof(float), hipMemcpyHostToDevice));
+    s->bf.xu = s->d_xu_own; s->bf.x_s = s->d_xs_own; s->bf.ref = s->d_ref_own;
+    s->last_stream = nullptr;
+    int rc = s->plant == GATO_PLANT_INDY7 ? stage_impl<Indy7>(s, stage, dt, out) : stage_impl<Iiwa14>(s, stage, dt, out);
+    if (rc) return rc;
+    HIPCHK(hipMemcpy(xu, s->d_xu_own, nxu, hipMemcpyDeviceToHost));
+    return GATO_OK;
+}
+
+extern "C" int gato_set_profiling(GatoSolver* s, int enabled)
+{
+    if (!s) return fail(GATO_ERR_INVALID, "null solver");
+    s->profiling = enabled ? 1 : 0;
+    return GATO_OK;
+}
+extern "C" int gato_get_stage_times_us(GatoSolver* s, double* out7)
+{
+    if (!s || !out7) return fail(GATO_ERR_INVALID, "null argument");
+    int rc = sync_last(s);
+    if (rc) return rc;
+    collect_profile(s);
+    for (int i = 0; i <= ST_COUNT; i++) out7[i] = s->stage_us[i];
+    return GATO_OK;
+}
+
+extern "C" const char* gato_last_error(void) { return g_err.c_str(); }
+extern "C" const char* gato_version(void) { return "gato_amd 0.1.0 (gfx950)"; }

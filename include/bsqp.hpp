@@ -1,0 +1,130 @@
+// bsqp.hpp -- the reference's C++ solver API `template<typename T, uint32_t BatchSize> class BSQP` (gato/bsqp/bsqp.cuh:20-197) and its
+// companion structs (gato/types.cuh:13-59) as a header-only wrapper over the C ABI of libgato_hip.so, so that the reference's
+// C++ example (examples/bsqp.cu:7-77) compiles against this library after its cuda* -> hip* renames.  float only (the C ABI is
+// fp32 like the reference's default `typedef float T`, settings.h:7-11).
+//
+// Plant and horizon are template/ctor arguments here instead of -D defines: BSQP<float, 16> solver(GATO_PLANT_INDY7, 16, dt, ...).
+// If GATO_PLANT and KNOT_POINTS macros are defined (the reference's build convention) they are the defaults.
+#pragma once
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "gato_abi.h"
+
+#ifndef GATO_PLANT
+#if defined(PLANT_IIWA14)
+#define GATO_PLANT GATO_PLANT_IIWA14
+#else
+#define GATO_PLANT GATO_PLANT_INDY7
+#endif
+#endif
+#ifndef KNOT_POINTS
+#define KNOT_POINTS 32
+#endif
+
+template<typename T, uint32_t BatchSize>
+struct ProblemInputs {  // gato/types.cuh:13-19
+    T timestep;
+    T* d_x_s_batch;             // STATE_SIZE * batch_size (device)
+    T* d_reference_traj_batch;  // 6 * KNOT_POINTS * batch_size (device)
+    void* d_GRiD_mem;           // unused: the robot tables are compile-time constants of the kernels
+};
+
+template<uint32_t BatchSize>
+struct PCGStats {  // gato/types.cuh:23-31
+    double solve_time_us = 0;
+    std::vector<int> num_iterations = std::vector<int>(BatchSize, 0);
+    std::vector<int> converged = std::vector<int>(BatchSize, 0);
+};
+
+template<typename T, uint32_t BatchSize>
+struct LineSearchStats {  // gato/types.cuh:35-42
+    std::vector<T> min_merit = std::vector<T>(BatchSize, 0);
+    std::vector<T> step_size = std::vector<T>(BatchSize, 0);
+};
+
+template<typename T, uint32_t BatchSize>
+struct SQPStats {  // gato/types.cuh:46-59
+    double solve_time_us = 0;
+    std::vector<int> sqp_iterations = std::vector<int>(BatchSize, 0);
+    std::vector<int> kkt_converged = std::vector<int>(BatchSize, 0);
+    std::vector<PCGStats<BatchSize>> pcg_stats;
+    std::vector<LineSearchStats<T, BatchSize>> line_search_stats;
+};
+
+template<typename T, uint32_t BatchSize>
+class BSQP {
+    static_assert(sizeof(T) == sizeof(float), "libgato_hip is fp32");
+
+  public:
+    BSQP(int plant = GATO_PLANT, int knot_points = KNOT_POINTS)
+    {
+        GatoParams p;
+        gato_default_params(&p);
+        init(plant, knot_points, p);
+    }
+    BSQP(T dt, uint32_t max_sqp_iters, T kkt_tol, uint32_t max_pcg_iters, T pcg_tol, T solve_ratio, T mu, T q_cost, T qd_cost, T u_cost, T N_cost,
+         T q_lim_cost, T vel_lim_cost, T ctrl_lim_cost, T rho, int plant = GATO_PLANT, int knot_points = KNOT_POINTS)
+    {
+        GatoParams p{dt, max_sqp_iters, kkt_tol, max_pcg_iters, pcg_tol, solve_ratio, mu, q_cost, qd_cost, u_cost, N_cost, q_lim_cost, vel_lim_cost, ctrl_lim_cost, rho};
+        init(plant, knot_points, p);
+    }
+    ~BSQP() { gato_destroy(s_); }
+    BSQP(const BSQP&) = delete;
+    BSQP& operator=(const BSQP&) = delete;
+
+    void set_f_ext_batch(T* h) { chk(gato_set_f_ext_batch(s_, h)); }
+    void set_rho_penalty_batch(const T* h, bool set_as_reset_default = true) { chk(gato_set_rho_penalty_batch(s_, h, set_as_reset_default)); }
+    void set_drho_batch(const T* h, bool set_as_reset_default = true) { chk(gato_set_drho_batch(s_, h, set_as_reset_default)); }
+    void set_mu_batch(const T* h) { chk(gato_set_mu_batch(s_, h)); }
+    void set_pcg_tol_batch(const T* h) { chk(gato_set_pcg_tol_batch(s_, h)); }
+    void reset_dual() { chk(gato_reset_dual(s_)); }
+    void reset_rho() { chk(gato_reset_rho(s_)); }
+    void set_rho_adaptation(bool enabled) { chk(gato_set_rho_adaptation(s_, enabled)); }
+    void copy_final_merit_to_host(T* h_out) { chk(gato_get_final_merit(s_, h_out)); }
+    void copy_initial_merit0_to_host(T* h_out) { chk(gato_get_initial_merit(s_, h_out)); }
+
+    // device-pointer solve, blocking like the reference's (its loop synchronises on the pageable D2H copies, bsqp.cuh:137,184)
+    SQPStats<T, BatchSize> solve(T* d_xu_traj_batch, ProblemInputs<T, BatchSize> inputs)
+    {
+        chk(gato_solve_device(s_, d_xu_traj_batch, inputs.timestep, inputs.d_x_s_batch, inputs.d_reference_traj_batch, nullptr));
+        SQPStats<T, BatchSize> st;
+        uint32_t iters = 0, ls = 0;
+        chk(gato_get_counts(s_, &iters, &ls));
+        chk(gato_get_sqp_iters(s_, st.sqp_iterations.data()));
+        chk(gato_get_kkt_converged(s_, st.kkt_converged.data()));
+        std::vector<int32_t> pcg((size_t)(iters ? iters : 1) * BatchSize);
+        std::vector<T> mm((size_t)(ls ? ls : 1) * BatchSize), ss((size_t)(ls ? ls : 1) * BatchSize);
+        chk(gato_get_pcg_iters(s_, pcg.data()));
+        chk(gato_get_ls_min_merit(s_, mm.data()));
+        chk(gato_get_ls_step_size(s_, ss.data()));
+        for (uint32_t i = 0; i < iters; i++) {
+            PCGStats<BatchSize> ps;
+            for (uint32_t b = 0; b < BatchSize; b++) ps.num_iterations[b] = pcg[(size_t)i * BatchSize + b];
+            st.pcg_stats.push_back(ps);
+        }
+        for (uint32_t i = 0; i < ls; i++) {
+            LineSearchStats<T, BatchSize> l;
+            for (uint32_t b = 0; b < BatchSize; b++) {
+                l.min_merit[b] = mm[(size_t)i * BatchSize + b];
+                l.step_size[b] = ss[(size_t)i * BatchSize + b];
+            }
+            st.line_search_stats.push_back(l);
+        }
+        double t[7];
+        if (gato_get_stage_times_us(s_, t) == GATO_OK) st.solve_time_us = t[6];
+        return st;
+    }
+
+    GatoSolver* handle() { return s_; }
+
+  private:
+    void init(int plant, int knot_points, const GatoParams& p) { chk(gato_create(plant, knot_points, (int)BatchSize, &p, &s_)); }
+    static void chk(int rc)
+    {
+        if (rc != GATO_OK) throw std::runtime_error(std::string("libgato_hip: ") + gato_last_error());
+    }
+    GatoSolver* s_ = nullptr;
+};

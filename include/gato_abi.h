@@ -1,0 +1,127 @@
+/*
+ * gato_abi.h -- C ABI of libgato_hip.so, the MI355X-native batched SQP solver.
+ *
+ * This is the drop-in boundary for the reference's batched-SQP path: every entry point below replaces one member of the
+ * reference's `BSQP<T,BatchSize>` C++ class (gato/bsqp/bsqp.cuh) / its pybind11 wrapper `PyBSQP<T,B>` (python/bindings.cu).
+ * Plain pointers and sizes only, no exceptions across the boundary: every function returns GATO_OK (0) or a negative status,
+ * and gato_last_error() gives the text.  Plant and horizon are run-time parameters here (the reference bakes them in at
+ * compile time: -DPLANT_* -DKNOT_POINTS, CMakeLists.txt:57-83); the batch size is run-time too (template parameter there).
+ *
+ * Layouts are the reference's (gato/utils/linalg.cuh:545-672), all float32, C-contiguous:
+ *   xu    [B][TRAJ]      TRAJ = (nx+nu) N - nu, knot = [x_k (nx), u_k (nu)], last knot x only
+ *   x_s   [B][nx]        nx = 2 nq, nu = nq  (indy7 nq = 6, iiwa14 nq = 7)
+ *   ref   [B][N][6]      end-effector reference, xyz + 3 unused
+ *   f_ext [B][6]         wrench on the last link, link-local frame
+ *
+ * Threading: one host thread per solver handle; a handle is bound to the HIP device that was current at gato_create.
+ */
+#ifndef GATO_ABI_H
+#define GATO_ABI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GATO_OK 0
+#define GATO_ERR_INVALID (-1)   /* bad argument (unsupported plant / N / B, null pointer) */
+#define GATO_ERR_HIP (-2)       /* a HIP runtime call failed; see gato_last_error() */
+#define GATO_ERR_NO_DEVICE (-3) /* no gfx950-capable device visible */
+
+#define GATO_PLANT_INDY7 0
+#define GATO_PLANT_IIWA14 1
+
+typedef struct GatoSolver GatoSolver;
+
+/* The 15 scalars of BSQP's second constructor, in its order (gato/bsqp/bsqp.cuh:43-45; python/bindings.cu:35-56). */
+typedef struct GatoParams {
+    float dt;
+    uint32_t max_sqp_iters;
+    float kkt_tol; /* accepted and unused, as in the reference (bsqp.cuh:153) */
+    uint32_t max_pcg_iters;
+    float pcg_tol;
+    float solve_ratio;
+    float mu;
+    float q_cost, qd_cost, u_cost, N_cost, q_lim_cost, vel_lim_cost, ctrl_lim_cost;
+    float rho;
+} GatoParams;
+
+/* Fills *p with the defaults of BSQP's first constructor (bsqp.cuh:24-27). */
+void gato_default_params(GatoParams* p);
+
+/* Sizes for a plant / horizon: nq, nx, nu, TRAJ.  Returns GATO_ERR_INVALID for an unknown plant. */
+int gato_dims(int plant, int knot_points, int* nq, int* nx, int* nu, int* traj_size);
+
+/* BSQP<T,B>::BSQP(...) + allocateMemory() (bsqp.cuh:43-59, 200-256).  knot_points: power of two in [4, 256] (the reference builds
+ * 8..128, CMakeLists.txt:46); batch >= 1 (the reference registers 1..1024, bindings.cu:254-264). */
+int gato_create(int plant, int knot_points, int batch, const GatoParams* params, GatoSolver** out);
+/* ~BSQP() (bsqp.cuh:61) */
+int gato_destroy(GatoSolver* s);
+
+/* PyBSQP::solve (python/bindings.cu:68-148) with host buffers: H2D of xu, x_s, ref; BSQP::solve; D2H of xu.
+ * xu is updated in place.  sqp_time_us (may be NULL) receives the host wall time of the device-synchronised SQP loop with the
+ * reference's meaning (bsqp.cuh:109,185,190: copies excluded). */
+int gato_solve(GatoSolver* s, float* xu, float timestep, const float* x_s, const float* ref, double* sqp_time_us);
+
+/* BSQP::solve (bsqp.cuh:103-197) on device pointers, enqueued on `stream` (a hipStream_t, NULL = default stream) WITHOUT a host
+ * synchronisation: the caller synchronises the stream before reading d_xu or calling the gato_get_* functions. */
+int gato_solve_device(GatoSolver* s, float* d_xu, float timestep, const float* d_x_s, const float* d_ref, void* stream);
+
+/* Stream-ordered variants for callers that keep everything on one HIP stream (bench.py, the multi-GPU layer): the resets of
+ * bsqp.cuh:81-87 as device-side copies enqueued on `stream`, and the final merits copied device-to-device into d_out [B]. */
+int gato_reset_async(GatoSolver* s, int reset_dual, int reset_rho, void* stream);
+int gato_copy_final_merit_device(GatoSolver* s, float* d_out, void* stream);
+
+/* Statistics of the last solve = the fields of SQPStats / the result dict of PyBSQP::solve (gato/types.cuh:23-59,
+ * python/bindings.cu:96-145).  Synchronises the solver's last stream.
+ *   iters_done    outer iterations executed (== every entry of sqp_iters)
+ *   ls_num_iters  line searches executed (one less than iters_done when the solve_ratio exit fired) */
+int gato_get_counts(GatoSolver* s, uint32_t* iters_done, uint32_t* ls_num_iters);
+int gato_get_sqp_iters(GatoSolver* s, int32_t* out /* [B] */);
+int gato_get_kkt_converged(GatoSolver* s, int32_t* out /* [B] */);
+int gato_get_final_merit(GatoSolver* s, float* out /* [B] */);   /* BSQP::copy_final_merit_to_host, bsqp.cuh:93-96 */
+int gato_get_initial_merit(GatoSolver* s, float* out /* [B] */); /* BSQP::copy_initial_merit0_to_host, bsqp.cuh:98-101 */
+int gato_get_pcg_iters(GatoSolver* s, int32_t* out /* [iters_done][B] */);
+int gato_get_ls_min_merit(GatoSolver* s, float* out /* [ls_num_iters][B] */);
+int gato_get_ls_step_size(GatoSolver* s, float* out /* [ls_num_iters][B] */);
+
+/* Setters, host arrays of length B (6 B for the wrench): bsqp.cuh:63-89. */
+int gato_set_f_ext_batch(GatoSolver* s, const float* f_ext);
+int gato_set_rho_penalty_batch(GatoSolver* s, const float* rho, int set_as_reset_default);
+int gato_set_drho_batch(GatoSolver* s, const float* drho, int set_as_reset_default);
+int gato_set_mu_batch(GatoSolver* s, const float* mu);
+int gato_set_pcg_tol_batch(GatoSolver* s, const float* pcg_tol);
+int gato_reset_dual(GatoSolver* s);
+int gato_reset_rho(GatoSolver* s);
+int gato_set_rho_adaptation(GatoSolver* s, int enabled);
+
+/* BSQP::sim_forward / PyBSQP::sim_forward (bsqp.cuh:91, bindings.cu:180-194): one integrator step of the SHARED (xk, uk) under the
+ * B stored wrench hypotheses; xkp1 is [B][nx] on the host. */
+int gato_sim_forward(GatoSolver* s, float* xkp1, const float* xk, const float* uk, float dt);
+
+/* End-effector positions [n][3] of n joint configurations [n][nq] (host arrays): what interface.BSQP.ee_pos obtains from
+ * pinocchio in the reference (python/bsqp/interface.py:212-214), computed with the solver's own kinematics. */
+int gato_ee_pos(GatoSolver* s, const float* q, int n, float* out);
+
+/* Debug / test access to a device buffer by name ("xu" is not owned and not available):
+ * "D","Qq","Qd","Rd","q","r","c","Qqi","Qdi","Rdi","S","Pinv","gamma","lambda","dz","merit","merit_cur","rho","drho", "step".
+ * Copies `count` floats to `out`; returns the buffer length in floats through *len when out == NULL. */
+int gato_debug_read(GatoSolver* s, const char* name, float* out, uint64_t count, uint64_t* len);
+int gato_debug_write(GatoSolver* s, const char* name, const float* in, uint64_t count);
+/* Runs ONE stage of an SQP iteration on device buffers previously filled (tests drive the stages one at a time):
+ * stage: 0 merit(8 alphas) 1 kkt 2 schur(+stair) 3 pcg 4 dz 5 line-search 6 merit(1, dz ignored) */
+int gato_debug_stage(GatoSolver* s, int stage, float* xu, float timestep, const float* x_s, const float* ref, float* out);
+
+/* Per-stage device time of the last gato_solve / gato_solve_device call when profiling was enabled (hipEvents around each
+ * kernel family): out[7] = {merit, kkt, schur, pcg, dz, line_search, total} in microseconds, summed over the iterations. */
+int gato_set_profiling(GatoSolver* s, int enabled);
+int gato_get_stage_times_us(GatoSolver* s, double* out7);
+
+const char* gato_last_error(void);
+const char* gato_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GATO_ABI_H */

@@ -1,0 +1,115 @@
+"""The drop-in boundary without a GPU: libgato_hip.so loads and exports every symbol include/gato_abi.h declares, the pure-host
+entry points behave, the C++ wrapper header compiles, and the product refuses to run without its HIP library (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "gato_abi.h")
+LIB = os.path.join(ROOT, "gato_amd", "csrc", "libgato_hip.so")
+
+
+def _declared():
+    txt = open(HEADER).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(gato_[a-z0-9_]+)\s*\(", txt)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(LIB):
+        import __graft_entry__ as g
+        g.build()
+    return C.CDLL(LIB)
+
+
+def test_every_declared_symbol_is_exported(lib):
+    names = _declared()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(lib, n), "libgato_hip.so does not export %s" % n
+    from gato_amd import _lib
+    assert sorted(_lib.SYMBOLS) == names  # the ctypes binding covers exactly the header
+
+
+def test_host_only_entry_points(lib):
+    from gato_amd._lib import GatoParams
+    p = GatoParams()
+    lib.gato_default_params(C.byref(p))
+    assert (p.max_sqp_iters, p.max_pcg_iters) == (5, 100) and abs(p.rho - 1e-3) < 1e-9 and abs(p.mu - 10) < 1e-6  # bsqp.cuh:24-27
+    nq, nx, nu, tr = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    assert lib.gato_dims(0, 32, C.byref(nq), C.byref(nx), C.byref(nu), C.byref(tr)) == 0
+    assert (nq.value, nx.value, nu.value, tr.value) == (6, 12, 6, 570)
+    assert lib.gato_dims(1, 128, C.byref(nq), C.byref(nx), C.byref(nu), C.byref(tr)) == 0
+    assert (nq.value, tr.value) == (7, 2681)
+    assert lib.gato_dims(7, 8, None, None, None, None) == -1
+    lib.gato_version.restype = C.c_char_p
+    assert b"gfx950" in lib.gato_version()
+
+
+def test_create_rejects_bad_arguments(lib):
+    from gato_amd._lib import GatoParams
+    p = GatoParams()
+    lib.gato_default_params(C.byref(p))
+    h = C.c_void_p()
+    lib.gato_last_error.restype = C.c_char_p
+    assert lib.gato_create(5, 32, 4, C.byref(p), C.byref(h)) == -1      # unknown plant
+    assert lib.gato_create(0, 33, 4, C.byref(p), C.byref(h)) == -1      # N not a power of two
+    assert lib.gato_create(0, 32, 0, C.byref(p), C.byref(h)) == -1      # empty batch
+    assert lib.gato_create(0, 32, 4, None, C.byref(h)) == -1
+    assert b"" != lib.gato_last_error()
+
+
+def test_no_cpu_fallback():
+    """Without a GPU the product raises; it never routes through the oracle."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from gato_amd._lib import GatoError, NativeSolver
+    with pytest.raises(GatoError):
+        NativeSolver("indy7", 8, 1)
+    src = ""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "gato_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                src += open(os.path.join(dirpath, f)).read()
+    assert "oracle" not in src.replace("CPU oracle", "").replace("the oracle", "").lower() or "import oracle" not in src
+    assert "from oracle" not in src and "import oracle" not in src and "libgato_oracle" not in src
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from gato_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libgato_hip.so")
+    with pytest.raises(_lib.GatoError, match="not built"):
+        _lib.load()
+
+
+def test_cpp_wrapper_header_compiles(tmp_path):
+    """include/bsqp.hpp mirrors `BSQP<T,B>` (bsqp.cuh:20-197); compile a translation unit shaped like examples/bsqp.cu:7-77."""
+    src = tmp_path / "use_bsqp.cpp"
+    src.write_text(r'''
+#include "bsqp.hpp"
+int main() {
+    constexpr uint32_t B = 16;
+    float zero = 0.f;
+    BSQP<float, B>* solver = nullptr;
+    try {
+        solver = new BSQP<float, B>(0.01f, 5u, 1e-3f, 100u, 1e-4f, 1.0f, 10.f, zero, zero, zero, zero, zero, zero, zero, zero, GATO_PLANT_INDY7, 16);
+    } catch (const std::exception&) { return 0; }  // no GPU in the authoring container
+    ProblemInputs<float, B> in{0.01f, nullptr, nullptr, nullptr};
+    (void)in;
+    solver->reset_dual(); solver->reset_rho(); solver->set_rho_adaptation(true);
+    delete solver;
+    return 0;
+}
+''')
+    exe = tmp_path / "use_bsqp"
+    subprocess.check_call(["g++", "-std=c++17", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe), LIB, "-Wl,-rpath," + os.path.dirname(LIB)])
+    env = dict(os.environ)
+    assert subprocess.call([str(exe)], env=env) == 0

@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Quick device timing of the full solve with per-stage hipEvent breakdown (debug aid; needs a GPU)."""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from gato_amd._lib import NativeSolver  # noqa: E402
+from gato_amd.bsqp.config import DEFAULT_SOLVER_PARAMS  # noqa: E402
+from gato_amd.bsqp.workloads import fig8_problem  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--plant", default="indy7")
+ap.add_argument("-N", type=int, default=32)
+ap.add_argument("-B", type=int, default=1024)
+ap.add_argument("--iters", type=int, default=10)
+ap.add_argument("--reps", type=int, default=5)
+a = ap.parse_args()
+p = dict(DEFAULT_SOLVER_PARAMS)
+p["max_sqp_iters"] = a.iters
+pr = fig8_problem(a.plant, a.N, a.B)
+s = NativeSolver(a.plant, a.N, a.B, dt=0.01, **p)
+s.set_profiling(True)
+ts = []
+for r in range(a.reps):
+    s.reset_dual(); s.reset_rho()
+    out = s.solve(pr["xu"], 0.01, pr["x_s"], pr["ref"])
+    ts.append(out["sqp_time_us"])
+    st = s.stage_times_us()
+print(a.plant, "N", a.N, "B", a.B, "iters", out["iters_done"], "ls", out["ls_num_iters"], "mean pcg", out["pcg_iters_all"].mean())
+print("sqp_time_us:", ["%.0f" % t for t in ts], " -> traj-iter/s %.3e" % (a.B * out["iters_done"] / (min(ts) * 1e-6)))
+print("stage us:", {k: round(v, 1) for k, v in st.items()})
+print("merit", out["initial_merit"][:3], "->", out["final_merit"][:3])
