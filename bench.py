@@ -71,23 +71,35 @@ def cpu_baseline(plant, N, params, dt, sample_b):
 
     def run(i):
         sl = slice(i * per, (i + 1) * per)
+        solvers[i].reset_dual()
+        solvers[i].reset_rho()
         return solvers[i].solve(pr["xu"][sl], dt, pr["x_s"][sl], pr["ref"][sl])["iters_done"]
 
-    warm = OracleSolver(plant, N, 1, dt=dt, threads=1, **params)
-    warm.solve(pr["xu"][:1], dt, pr["x_s"][:1], pr["ref"][:1])   # library load, page faults
+    import threading
+    gate = threading.Barrier(cores)
+    warm = [OracleSolver(plant, N, 1, dt=dt, threads=1, **dict(params, max_sqp_iters=1)) for _ in range(cores)]
+
+    def warm_up(i):   # every pool thread enters the library once before the clock starts (thread start-up, OpenMP per-thread init, page faults)
+        gate.wait()
+        warm[i].solve(pr["xu"][:1], dt, pr["x_s"][:1], pr["ref"][:1])
+
     with ThreadPoolExecutor(cores) as ex:
-        list(ex.map(lambda i: i, range(cores)))
-        t0 = time.perf_counter()
-        iters = list(ex.map(run, range(cores)))   # ctypes releases the GIL inside orc_solve
-        t = time.perf_counter() - t0
+        list(ex.map(warm_up, range(cores)))
+        t = float("inf")
+        for _ in range(3):                            # best of 3 passes: the first pass on a cold host runs several times slower
+            t0 = time.perf_counter()
+            iters = list(ex.map(run, range(cores)))   # ctypes releases the GIL inside orc_solve
+            t = min(t, time.perf_counter() - t0)
     rate = per * sum(iters) / t
+    solvers[0].reset_dual()
+    solvers[0].reset_rho()
     t0 = time.perf_counter()
     o1 = solvers[0].solve(pr["xu"][:per], dt, pr["x_s"][:per], pr["ref"][:per])
     t1 = time.perf_counter() - t0
     single = per * o1["iters_done"] / t1
     return {"value": rate, "unit": "traj-SQP-iter/s", "cores": cores, "kind": "port",
             "sample": "first %d trajectories of the same workload, %d SQP iterations each, %d single-threaded oracle solvers side by side "
-                      "(%.2f s); one thread alone: %.0f traj-SQP-iter/s" % (sample_b, iters[0], cores, t, single),
+                      "(best of 3 passes, %.2f s); one thread alone: %.0f traj-SQP-iter/s" % (sample_b, iters[0], cores, t, single),
             "single_core_value": single}
 
 

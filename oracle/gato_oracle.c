@@ -51,6 +51,7 @@ typedef struct {
     /* KKT + Schur buffers (gato/types.cuh:63-81) */
     float *Q, *R, *q, *r, *A, *Bm, *c, *Qinv, *Rinv, *S, *Pinv, *gamma, *dz;
     float *merit, *merit_cur, *merit_init0, *step;
+    float* pcg_work; /* [B][5 * vecp] */
     int32_t* converged;
     uint32_t* pcg_iters;
     /* stats of the last solve */
@@ -753,7 +754,8 @@ static void pcg_one(Orc* o, int b)
     const float* bvec = o->gamma + (size_t)b * n;
     float* xg = o->lambda + (size_t)b * n;
     float eps = o->pcg_tol[b];
-    float* w = (float*)calloc((size_t)5 * n, sizeof(float));
+    float* w = o->pcg_work + (size_t)b * 5 * n; /* block::zeroSharedMemory, pcg.cuh:37 */
+    memset(w, 0, (size_t)5 * n * sizeof(float));
     float *Ap = w, *x = w + n, *r = w + 2 * n, *z = w + 3 * n, *pv = w + 4 * n;
     memcpy(x, xg, n * sizeof(float));
     btd_matvec(N, nx, r, S, x);
@@ -762,7 +764,7 @@ static void pcg_one(Orc* o, int b)
     memcpy(pv, z, n * sizeof(float));
     float rho = dotv(n, r, z);
     uint32_t iters = 0;
-    if (fabsf(rho) < abs_tol) { o->pcg_iters[b] = 0; free(w); return; }
+    if (fabsf(rho) < abs_tol) { o->pcg_iters[b] = 0; return; }
     float rho_init = fabsf(rho);
     for (uint32_t i = 0; i < o->p.max_pcg_iters; i++) {
         iters++;
@@ -778,7 +780,6 @@ static void pcg_one(Orc* o, int b)
     }
     o->pcg_iters[b] = iters;
     memcpy(xg, x, n * sizeof(float));
-    free(w);
 }
 
 /* computeDzBatchedKernel (gato/bsqp/kernels/schur_linsys.cuh:316-431) for one trajectory; q,r become the KKT residuals */
@@ -925,6 +926,7 @@ Orc* orc_create(int plant, int N, int B, const OrcParams* p)
     o->Qinv = ALLOCF(BN * nx * nx); o->Rinv = ALLOCF(BN * nu * nu);
     o->S = ALLOCF(BN * o->brow); o->Pinv = ALLOCF(BN * o->brow); o->gamma = ALLOCF((size_t)B * o->vecp);
     o->dz = ALLOCF((size_t)B * o->traj);
+    o->pcg_work = ALLOCF((size_t)B * 5 * o->vecp);
     o->merit = ALLOCF((size_t)B * NUM_ALPHAS); o->merit_cur = ALLOCF(B); o->merit_init0 = ALLOCF(B); o->step = ALLOCF(B);
     o->converged = (int32_t*)calloc(B, sizeof(int32_t));
     o->pcg_iters = (uint32_t*)calloc(B, sizeof(uint32_t));
@@ -940,7 +942,7 @@ void orc_destroy(Orc* o)
 {
     if (!o) return;
     float* fl[] = {o->lambda, o->rho, o->drho, o->rho_init, o->drho_init, o->mu, o->pcg_tol, o->f_ext, o->Q, o->R, o->q, o->r, o->A, o->Bm,
-                   o->c, o->Qinv, o->Rinv, o->S, o->Pinv, o->gamma, o->dz, o->merit, o->merit_cur, o->merit_init0, o->step, o->st_min_merit, o->st_step};
+                   o->c, o->Qinv, o->Rinv, o->S, o->Pinv, o->gamma, o->dz, o->merit, o->merit_cur, o->merit_init0, o->step, o->st_min_merit, o->st_step, o->pcg_work};
     for (size_t i = 0; i < sizeof(fl) / sizeof(fl[0]); i++) free(fl[i]);
     free(o->converged); free(o->pcg_iters); free(o->st_pcg_iters); free(o->sqp_iters); free(o->kkt_converged);
     free(o);
