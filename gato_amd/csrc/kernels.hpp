@@ -694,36 +694,53 @@ __global__ __launch_bounds__(64) void schur2_kernel(Buffers bf, int N, int B)
 // =========================================================================================================================
 template<int NXT> GATO_DEV float row_dot(const float* __restrict__ row, const float* __restrict__ win)
 {
-    // win: LDS window of 3 nx floats starting at the left-neighbour block (16-byte aligned when nx % 4 == 0)
-    float s = 0.f;
+    // win: LDS window of 3 nx floats starting at the left-neighbour block (16-byte aligned when nx % 4 == 0).
+    // Four independent accumulators: the FMA chain no longer serialises behind the LDS reads.
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if constexpr ((3 * NXT) % 4 == 0 && NXT % 4 == 0) {
 #pragma unroll
         for (int c = 0; c < 3 * NXT / 4; c++) {
             const float4 v = reinterpret_cast<const float4*>(win)[c];
-            s += row[4 * c] * v.x;
-            s += row[4 * c + 1] * v.y;
-            s += row[4 * c + 2] * v.z;
-            s += row[4 * c + 3] * v.w;
+            s0 += row[4 * c] * v.x;
+            s1 += row[4 * c + 1] * v.y;
+            s2 += row[4 * c + 2] * v.z;
+            s3 += row[4 * c + 3] * v.w;
         }
     } else {
 #pragma unroll
         for (int c = 0; c < 3 * NXT / 2; c++) {
             const float2 v = reinterpret_cast<const float2*>(win)[c];
-            s += row[2 * c] * v.x;
-            s += row[2 * c + 1] * v.y;
+            if (c & 1) { s2 += row[2 * c] * v.x; s3 += row[2 * c + 1] * v.y; }
+            else { s0 += row[2 * c] * v.x; s1 += row[2 * c + 1] * v.y; }
         }
     }
-    return s;
+    return (s0 + s1) + (s2 + s3);
 }
 
-GATO_DEV float block_sum(float v, float* part, int nwaves)
+// wave64 sum with DPP row operations (no LDS crossbar traffic, unlike ds_bpermute-based __shfl): quad butterflies, half-row and
+// row mirrors, then row_bcast15 / row_bcast31 accumulate the four 16-lane rows into lane 63, which is broadcast back.
+GATO_DEV float wave_sum(float v)
 {
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+#define GATO_DPP_ADD(ctrl, rmask) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, rmask, 0xf, false))
+    GATO_DPP_ADD(0xB1, 0xf);   // quad_perm [1,0,3,2]
+    GATO_DPP_ADD(0x4E, 0xf);   // quad_perm [2,3,0,1]
+    GATO_DPP_ADD(0x141, 0xf);  // row_half_mirror
+    GATO_DPP_ADD(0x140, 0xf);  // row_mirror: every lane holds its row's sum
+    GATO_DPP_ADD(0x142, 0xa);  // row_bcast15 into rows 1 and 3
+    GATO_DPP_ADD(0x143, 0xc);  // row_bcast31 into rows 2 and 3: lane 63 holds the wave's sum
+#undef GATO_DPP_ADD
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+// block-wide sum; `part` has 16 slots (unused ones zeroed once by the caller), read back with four 16-byte LDS loads
+GATO_DEV float block_sum(float v, float* part)
+{
+    v = wave_sum(v);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
     __syncthreads();
-    float s = 0.f;
-    for (int i = 0; i < nwaves; i++) s += part[i];
-    return s;
+    const float4 a = reinterpret_cast<const float4*>(part)[0], b = reinterpret_cast<const float4*>(part)[1];
+    const float4 c = reinterpret_cast<const float4*>(part)[2], d = reinterpret_cast<const float4*>(part)[3];
+    return (((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w))) + (((c.x + c.y) + (c.z + c.w)) + ((d.x + d.y) + (d.z + d.w)));
 }
 
 // RPT rows per thread; STREAM = false keeps the thread's S / P^-1 rows in registers, true re-reads them from global memory
@@ -735,12 +752,13 @@ __global__ __launch_bounds__(MAXT) void pcg_kernel(Buffers bf, int N, int B, uin
     extern __shared__ __attribute__((aligned(16))) float lds[];
     if (bf.ctrl->done) return;
     const int b = blockIdx.x;
-    const int T = blockDim.x, nwaves = T >> 6;
+    const int T = blockDim.x;
     const int nrows = N * NX, vecp = (N + 2) * NX;
     float* va = lds;               // padded vector A (x, then p)
     float* vb = lds + vecp;        // padded vector B (r)
-    float* partA = vb + vecp;      // [16]
-    float* partB = partA + 16;     // [16]
+    float* partA = vb + ((vecp + 3) & ~3);  // [16], 16-byte aligned
+    float* partB = partA + 16;               // [16]
+    if (threadIdx.x < 32) partA[threadIdx.x] = 0.f;  // unused wave slots stay zero (published by the first barrier below)
     const float abs_tol = 1e-6f;
     uint32_t iters = 0;
     const bool skip = bf.converged[b] != 0;  // pcg.cuh:29-32
@@ -822,7 +840,7 @@ __global__ __launch_bounds__(MAXT) void pcg_kernel(Buffers bf, int N, int B, uin
             pv[u] = zv[u];
             loc += rv[u] * zv[u];
         }
-        float rho = block_sum(loc, partA, nwaves);
+        float rho = block_sum(loc, partA);
         if (!(fabsf(rho) < abs_tol)) {
             const float rho_init = fabsf(rho);
             for (uint32_t it = 0; it < max_iters; it++) {
@@ -838,7 +856,7 @@ __global__ __launch_bounds__(MAXT) void pcg_kernel(Buffers bf, int N, int B, uin
                     Ap[u] = have[u] ? sdot(u, va + (row[u] / NX) * NX) : 0.f;
                     loc += pv[u] * Ap[u];
                 }
-                const float pAp = block_sum(loc, partB, nwaves);
+                const float pAp = block_sum(loc, partB);
                 const float alpha = rho / pAp;
 #pragma unroll
                 for (int u = 0; u < RPT; u++) {
@@ -853,7 +871,7 @@ __global__ __launch_bounds__(MAXT) void pcg_kernel(Buffers bf, int N, int B, uin
                     zv[u] = have[u] ? pdot(u, vb + (row[u] / NX) * NX) : 0.f;
                     loc += rv[u] * zv[u];
                 }
-                const float rho_new = block_sum(loc, partA, nwaves);
+                const float rho_new = block_sum(loc, partA);
                 if (fabsf(rho_new) < (abs_tol + eps * rho_init)) break;
                 const float beta = rho_new / rho;
                 rho = rho_new;
@@ -863,6 +881,151 @@ __global__ __launch_bounds__(MAXT) void pcg_kernel(Buffers bf, int N, int B, uin
 #pragma unroll
             for (int u = 0; u < RPT; u++)
                 if (have[u]) lam[NX + row[u]] = xv[u];
+        }
+    }
+    if (threadIdx.x == 0) {
+        bf.pcg_iters[b] = iters;
+        bf.st_pcg_iters[(size_t)sqp_iter * B + b] = (int32_t)iters;
+        int conv = skip ? 1 : 0;
+        if (iters == 0) { conv = 1; bf.converged[b] = 1; }  // bsqp.cuh:153-156 (kkt_tol is unused there)
+        if (conv) atomicAdd(&bf.num_solved[sqp_iter], 1u);
+    }
+}
+
+// ---- PCG, register-resident, contiguous rows ------------------------------------------------------------------------------
+// Thread t owns the RPT CONSECUTIVE rows [t*RPT, (t+1)*RPT) of the system; NX % RPT == 0, so they lie in ONE block row and share
+// the 3 nx-wide window of the input vector: one LDS read of the window feeds RPT rows (LDS traffic / RPT) and the RPT dot products
+// give the FMA stream its ILP.  With RPT = 6 an indy7 N = 32 trajectory is ONE wavefront (64 lanes x 6 rows): 432 matrix registers
+// per lane, no cross-wave barrier at all, and four trajectories co-resident per CU (one per SIMD).
+template<int NXT, int RPT> GATO_DEV void rows_dot(const float (*rows)[3 * NXT], const float* __restrict__ win, float* acc)
+{
+#pragma unroll
+    for (int u = 0; u < RPT; u++) acc[u] = 0.f;
+    if constexpr (NXT % 4 == 0) {
+#pragma unroll
+        for (int c = 0; c < 3 * NXT / 4; c++) {
+            const float4 v = reinterpret_cast<const float4*>(win)[c];
+#pragma unroll
+            for (int u = 0; u < RPT; u++) {
+                acc[u] += rows[u][4 * c] * v.x;
+                acc[u] += rows[u][4 * c + 1] * v.y;
+                acc[u] += rows[u][4 * c + 2] * v.z;
+                acc[u] += rows[u][4 * c + 3] * v.w;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < 3 * NXT / 2; c++) {
+            const float2 v = reinterpret_cast<const float2*>(win)[c];
+#pragma unroll
+            for (int u = 0; u < RPT; u++) {
+                acc[u] += rows[u][2 * c] * v.x;
+                acc[u] += rows[u][2 * c + 1] * v.y;
+            }
+        }
+    }
+}
+
+template<class M, int RPT, int MAXT>
+__global__ __launch_bounds__(MAXT) void pcgc_kernel(Buffers bf, int N, int B, uint32_t max_iters, int sqp_iter)
+{
+    constexpr int NQ = M::NQ, NX = 2 * NQ, BR = 3 * NX, BROW = 3 * NX * NX;
+    static_assert(NX % RPT == 0, "rows of one thread must share a block row");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    if (bf.ctrl->done) return;
+    const int b = blockIdx.x;
+    const int nrows = N * NX, vecp = (N + 2) * NX;
+    float* va = lds;
+    float* vb = lds + vecp;
+    float* partA = vb + ((vecp + 3) & ~3);
+    float* partB = partA + 16;
+    if (threadIdx.x < 32) partA[threadIdx.x] = 0.f;
+    const float abs_tol = 1e-6f;
+    uint32_t iters = 0;
+    const bool skip = bf.converged[b] != 0;  // pcg.cuh:29-32
+
+    if (!skip) {
+        const float eps = bf.pcg_tol[b];
+        const int r0 = threadIdx.x * RPT;
+        const bool have = r0 < nrows;  // blockDim.x * RPT >= nrows; whole threads are in or out
+        const int rr = have ? r0 : 0;
+        const int kb = rr / NX;
+        const float* gam = bf.gamma + (size_t)b * vecp;
+        float* lam = bf.lambda + (size_t)b * vecp;
+        float Srow[RPT][BR], Prow[RPT][BR], xv[RPT], rv[RPT], pv[RPT], zv[RPT], gv[RPT];
+        {
+            const float* S = bf.S + (size_t)b * N * BROW + (size_t)rr * BR;
+            const float* P = bf.Pinv + (size_t)b * N * BROW + (size_t)rr * BR;
+#pragma unroll
+            for (int u = 0; u < RPT; u++) {
+                load_vec<BR, NX>(Srow[u], S + u * BR);
+                load_vec<BR, NX>(Prow[u], P + u * BR);
+            }
+            load_vec<RPT, RPT>(xv, lam + NX + rr);
+            load_vec<RPT, RPT>(gv, gam + NX + rr);
+        }
+        const float* wa = va + kb * NX;
+        const float* wb = vb + kb * NX;
+        float* oa = va + NX + rr;
+        float* ob = vb + NX + rr;
+        for (int i = threadIdx.x; i < NX; i += blockDim.x) {
+            va[i] = 0.f; vb[i] = 0.f;
+            va[vecp - NX + i] = 0.f; vb[vecp - NX + i] = 0.f;
+        }
+        if (have) store_vec<RPT, RPT>(oa, xv);
+        __syncthreads();
+        float acc[RPT];
+        rows_dot<NX, RPT>(Srow, wa, acc);  // r = gamma - S x
+#pragma unroll
+        for (int u = 0; u < RPT; u++) rv[u] = have ? gv[u] - acc[u] : 0.f;
+        if (have) store_vec<RPT, RPT>(ob, rv);
+        __syncthreads();
+        rows_dot<NX, RPT>(Prow, wb, acc);  // z = p = P^-1 r
+        float loc = 0.f;
+#pragma unroll
+        for (int u = 0; u < RPT; u++) {
+            zv[u] = have ? acc[u] : 0.f;
+            pv[u] = zv[u];
+            loc += rv[u] * zv[u];
+        }
+        float rho = block_sum(loc, partA);
+        if (!(fabsf(rho) < abs_tol)) {
+            const float rho_init = fabsf(rho);
+            for (uint32_t it = 0; it < max_iters; it++) {
+                iters++;
+                if (have) store_vec<RPT, RPT>(oa, pv);
+                __syncthreads();
+                rows_dot<NX, RPT>(Srow, wa, acc);  // A p
+                loc = 0.f;
+#pragma unroll
+                for (int u = 0; u < RPT; u++) {
+                    if (!have) acc[u] = 0.f;
+                    loc += pv[u] * acc[u];
+                }
+                const float pAp = block_sum(loc, partB);
+                const float alpha = rho / pAp;
+#pragma unroll
+                for (int u = 0; u < RPT; u++) {
+                    xv[u] += alpha * pv[u];
+                    rv[u] -= alpha * acc[u];
+                }
+                if (have) store_vec<RPT, RPT>(ob, rv);
+                __syncthreads();
+                rows_dot<NX, RPT>(Prow, wb, acc);  // z = P^-1 r
+                loc = 0.f;
+#pragma unroll
+                for (int u = 0; u < RPT; u++) {
+                    zv[u] = have ? acc[u] : 0.f;
+                    loc += rv[u] * zv[u];
+                }
+                const float rho_new = block_sum(loc, partA);
+                if (fabsf(rho_new) < (abs_tol + eps * rho_init)) break;
+                const float beta = rho_new / rho;
+                rho = rho_new;
+#pragma unroll
+                for (int u = 0; u < RPT; u++) pv[u] = zv[u] + beta * pv[u];
+            }
+            if (have) store_vec<RPT, RPT>(lam + NX + rr, xv);
         }
     }
     if (threadIdx.x == 0) {
