@@ -319,6 +319,111 @@ template<int CNT, int ALIGN> GATO_DEV void load_vec(float* dst, const float* __r
     }
 }
 
+// Gauss-Jordan inverse without pivoting, the arithmetic of block::invertMatrix (linalg.cuh:364-519) on [V | I]:
+//   THREE = true : a / p * row   (2-/3-matrix overloads, used for Q_k, Q_{k+1}, R_k)
+//   THREE = false: a * (1/p) * row (1-matrix overload, used for theta_k and Q_0)
+// IN PLACE: at pivot p column p of V has become e_p in the augmented scheme and column p of the identity side is about to be
+// produced, so that column is stored in V's slot.  Every element sees exactly the operations (and operands) of the reference's
+// (n+1)-column sliding window -- columns outside the window are untouched there because their pivot-row entry is an exact 0 --
+// so the result is bit-identical to the augmented form at half the registers.  Mat is col-major n x n and returns the inverse.
+template<int n, bool THREE> GATO_DEV void gj_inverse(float* Mat)
+{
+#pragma unroll
+    for (int p = 0; p < n; p++) {
+        float colv[n];
+#pragma unroll
+        for (int i = 0; i < n; i++) colv[i] = Mat[p * n + i];
+        const float pv = colv[p];
+        const float pvInv = 1.0f / pv;
+#pragma unroll
+        for (int c = 0; c < n; c++) {
+            const float rowv = (c == p) ? 1.0f : Mat[c * n + p];
+#pragma unroll
+            for (int r = 0; r < n; r++) {
+                const float x = (c == p) ? ((r == p) ? 1.0f : 0.0f) : Mat[c * n + r];
+                float y;
+                if constexpr (THREE) {
+                    y = (r == p) ? x / pv : x - colv[r] / pv * rowv;
+                } else {
+                    y = (r == p) ? x * pvInv : x - colv[r] * pvInv * rowv;
+                }
+                Mat[c * n + r] = y;
+            }
+        }
+    }
+}
+
+// Column-split assembly: grid.y = NQ + 1.  Wavefronts with blockIdx.y = J < NQ compute, for 64 (b,k) problems, forward dynamics and
+// derivative column J (d qdd / d q_J, d qdd / d qd_J, M^-1[:, J]); J = 0 also stores the defect c_{k+1}.  The common prefix (M^-1,
+// two RNEA passes) is recomputed by each of the NQ waves -- 2.3x the instructions of the one-lane-does-all form, but NQ x the
+// wavefronts at half the registers, which is what a chip with 1024 SIMDs needs at B x N = 32768 problems.
+// blockIdx.y = NQ: cost blocks of knot k (and the terminal ones for k = N-2), their inverses (Q_k + rho I_q)^-1, R_k^-1 -- the
+// arithmetic of the 3-matrix Gauss-Jordan of schur_linsys.cuh:96 -- and c_0 = x_0 - x_s (lane k = N-1).
+template<class M, int J>
+GATO_DEV void kkt_column(const Buffers& bf, const float* x, const float* fe, size_t bk, float dt)
+{
+    constexpr int NQ = M::NQ, NX = 2 * NQ, NU = NQ, KS = NX + NU;
+    RBD<M> d;
+    d.set_q(x);
+    float cq[NQ], cd[NQ], cm[NQ];
+    d.template fd_grad_column<J>(x + NQ, x + NX, fe, cq, cd, cm, [&](const float* qdd) {
+        if constexpr (J == 0) {
+            float c[NX];
+#pragma unroll
+            for (int i = 0; i < NQ; i++) {
+                const float qdn = x[NQ + i] + dt * qdd[i];
+                const float qn = (float)((double)(x[i] + dt * x[NQ + i]) + 0.5 * (double)qdd[i] * (double)dt * (double)dt);
+                c[i] = x[KS + i] - qn;
+                c[NQ + i] = x[KS + NQ + i] - qdn;
+            }
+            store_vec<NX, NX>(bf.c + (bk + 1) * NX, c);
+        }
+    });
+    float* D = bf.D + bk * 3 * NQ * NQ;
+    store_vec<NQ, NQ>(D + J * NQ, cq);
+    store_vec<NQ, NQ>(D + NQ * NQ + J * NQ, cd);
+    store_vec<NQ, NQ>(D + 2 * NQ * NQ + J * NQ, cm);
+}
+
+template<class M>
+GATO_DEV void kkt_costs(const Buffers& bf, const Costs& cw, const float* x, const float* ref, size_t bk, float rho, bool terminal_too)
+{
+    constexpr int NQ = M::NQ, NX = 2 * NQ, NU = NQ;
+    RBD<M> d;
+    d.set_q(x);
+    float Qq[NQ * NQ], Qd[NQ], qv[NX], Rd[NU], rv[NU];
+    cost_blocks<M>(d, cw, x, x + NX, ref, Qq, Qd, qv, Rd, rv);
+    store_vec<NQ * NQ, NQ * NQ>(bf.Qq + bk * NQ * NQ, Qq);
+    store_vec<NQ, NQ>(bf.Qd + bk * NQ, Qd);
+    store_vec<NX, NX>(bf.q + bk * NX, qv);
+    store_vec<NU, NU>(bf.Rd + bk * NU, Rd);
+    store_vec<NU, NU>(bf.r + bk * NU, rv);
+#pragma unroll
+    for (int i = 0; i < NQ; i++) {
+        Qq[i * NQ + i] += rho;        // first nx/2 diagonal entries only (linalg.cuh:84-96)
+        Qd[i] = 1.0f / Qd[i];
+        Rd[i] = 1.0f / Rd[i];
+    }
+    gj_inverse<NQ, true>(Qq);
+    store_vec<NQ * NQ, NQ * NQ>(bf.Qqi + bk * NQ * NQ, Qq);
+    store_vec<NQ, NQ>(bf.Qdi + bk * NQ, Qd);
+    store_vec<NU, NU>(bf.Rdi + bk * NU, Rd);
+    if (terminal_too) {
+        cost_blocks<M>(d, cw, x, x + NX, ref + 6, Qq, Qd, qv, nullptr, nullptr);
+        store_vec<NQ * NQ, NQ * NQ>(bf.Qq + (bk + 1) * NQ * NQ, Qq);
+        store_vec<NQ, NQ>(bf.Qd + (bk + 1) * NQ, Qd);
+        store_vec<NX, NX>(bf.q + (bk + 1) * NX, qv);
+#pragma unroll
+        for (int i = 0; i < NQ; i++) {
+            Qq[i * NQ + i] += rho;
+            Qd[i] = 1.0f / Qd[i];
+        }
+        gj_inverse<NQ, true>(Qq);
+        store_vec<NQ * NQ, NQ * NQ>(bf.Qqi + (bk + 1) * NQ * NQ, Qq);
+        store_vec<NQ, NQ>(bf.Qdi + (bk + 1) * NQ, Qd);
+    }
+}
+
 template<class M>
 __global__ __launch_bounds__(64) void kkt_kernel(Buffers bf, Costs cw, int N, int B, float dt)
 {
@@ -326,107 +431,46 @@ __global__ __launch_bounds__(64) void kkt_kernel(Buffers bf, Costs cw, int N, in
     if (bf.ctrl->done) return;
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     const int k = g % N, b = g / N;
+    const int task = blockIdx.y;
     if (b >= B) return;
     const int traj = KS * N - NU;
     const float* xu = bf.xu + (size_t)b * traj + (size_t)k * KS;
     const size_t bk = (size_t)b * N + k;
     if (k == N - 1) {
-        float c0[NX];
-        const float* x0 = bf.xu + (size_t)b * traj;
+        if (task == NQ) {
+            float c0[NX];
+            const float* x0 = bf.xu + (size_t)b * traj;
 #pragma unroll
-        for (int i = 0; i < NX; i++) c0[i] = x0[i] - bf.x_s[(size_t)b * NX + i];
-        store_vec<NX, NX>(bf.c + (size_t)b * N * NX, c0);
+            for (int i = 0; i < NX; i++) c0[i] = x0[i] - bf.x_s[(size_t)b * NX + i];
+            store_vec<NX, NX>(bf.c + (size_t)b * N * NX, c0);
+        }
         return;
     }
     float x[KS + NX], fe[6];
 #pragma unroll
     for (int i = 0; i < KS + NX; i++) x[i] = xu[i];
+    if (task == NQ) {
+        kkt_costs<M>(bf, cw, x, bf.ref + (size_t)b * 6 * N + 6 * k, bk, bf.rho[b], k == N - 2);
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 6; i++) fe[i] = bf.f_ext[6 * b + i];
-    const float* ref = bf.ref + (size_t)b * 6 * N + 6 * k;
-
-    RBD<M> d;
-    d.set_q(x);
-    {
-        float qdd[NQ], Dq[NQ][NQ], Dd[NQ][NQ], c[NX];
-        typename RBD<M>::MinvT Mi;
-        d.forward_dynamics_grad(x + NQ, x + NX, fe, qdd, Dq, Dd, Mi);
-#pragma unroll
-        for (int i = 0; i < NQ; i++) {
-            const float qdn = x[NQ + i] + dt * qdd[i];
-            const float qn = (float)((double)(x[i] + dt * x[NQ + i]) + 0.5 * (double)qdd[i] * (double)dt * (double)dt);
-            c[i] = x[KS + i] - qn;
-            c[NQ + i] = x[KS + NQ + i] - qdn;
-        }
-        store_vec<NX, NX>(bf.c + (bk + 1) * NX, c);
-        float Dm[3 * NQ * NQ];
-#pragma unroll
-        for (int J = 0; J < NQ; J++)
-#pragma unroll
-            for (int r = 0; r < NQ; r++) {
-                Dm[J * NQ + r] = Dq[J][r];
-                Dm[NQ * NQ + J * NQ + r] = Dd[J][r];
-                Dm[2 * NQ * NQ + J * NQ + r] = Mi.sym(r, J);
-            }
-        store_vec<3 * NQ * NQ, 3 * NQ * NQ>(bf.D + bk * 3 * NQ * NQ, Dm);
-    }
-    {
-        float Qq[NQ * NQ], Qd[NQ], qv[NX], Rd[NU], rv[NU];
-        cost_blocks<M>(d, cw, x, x + NX, ref, Qq, Qd, qv, Rd, rv);
-        store_vec<NQ * NQ, NQ * NQ>(bf.Qq + bk * NQ * NQ, Qq);
-        store_vec<NQ, NQ>(bf.Qd + bk * NQ, Qd);
-        store_vec<NX, NX>(bf.q + bk * NX, qv);
-        store_vec<NU, NU>(bf.Rd + bk * NU, Rd);
-        store_vec<NU, NU>(bf.r + bk * NU, rv);
-        if (k == N - 2) {
-            cost_blocks<M>(d, cw, x, x + NX, ref + 6, Qq, Qd, qv, nullptr, nullptr);
-            store_vec<NQ * NQ, NQ * NQ>(bf.Qq + (bk + 1) * NQ * NQ, Qq);
-            store_vec<NQ, NQ>(bf.Qd + (bk + 1) * NQ, Qd);
-            store_vec<NX, NX>(bf.q + (bk + 1) * NX, qv);
-        }
+    switch (task) {  // wave-uniform
+        case 0: kkt_column<M, 0>(bf, x, fe, bk, dt); break;
+        case 1: kkt_column<M, 1>(bf, x, fe, bk, dt); break;
+        case 2: kkt_column<M, 2>(bf, x, fe, bk, dt); break;
+        case 3: kkt_column<M, 3>(bf, x, fe, bk, dt); break;
+        case 4: kkt_column<M, 4>(bf, x, fe, bk, dt); break;
+        case 5: kkt_column<M, 5>(bf, x, fe, bk, dt); break;
+        default:
+            if constexpr (NQ > 6) kkt_column<M, NQ - 1>(bf, x, fe, bk, dt);
+            break;
     }
 }
 
 // =========================================================================================================================
 // Schur complement formation (schur_linsys.cuh:14-211), one lane per (b,k).
 // =========================================================================================================================
-// Gauss-Jordan inverse without pivoting, the arithmetic of block::invertMatrix (linalg.cuh:364-519) on [V | I]:
-//   THREE = true : a / p * row   (2-/3-matrix overloads, used for Q_k, Q_{k+1}, R_k)
-//   THREE = false: a * (1/p) * row (1-matrix overload, used for theta_k and Q_0)
-// V (col-major n x n) is destroyed; W returns the inverse.
-template<int n, bool THREE> GATO_DEV void gj_inverse(float* V, float* W)
-{
-#pragma unroll
-    for (int i = 0; i < n * n; i++) W[i] = ((i / n) == (i % n)) ? 1.f : 0.f;
-#pragma unroll
-    for (int p = 0; p < n; p++) {
-        // augmented column index j in [p, p+n]: j < n -> V[:, j], else W[:, j-n]
-        float colv[n], rowv[n + 1];
-#pragma unroll
-        for (int i = 0; i < n; i++) colv[i] = V[p * n + i];
-#pragma unroll
-        for (int j = 0; j <= n; j++) {
-            const int cj = p + j;
-            rowv[j] = (cj < n) ? V[cj * n + p] : W[(cj - n) * n + p];
-        }
-        const float pv = colv[p];
-        const float pvInv = 1.0f / pv;
-#pragma unroll
-        for (int j = 0; j <= n; j++) {
-            const int cj = p + j;
-#pragma unroll
-            for (int r = 0; r < n; r++) {
-                float& x = (cj < n) ? V[cj * n + r] : W[(cj - n) * n + r];
-                if constexpr (THREE) {
-                    if (r == p) x = x / pv; else x -= colv[r] / pv * rowv[j];
-                } else {
-                    if (r == p) x *= pvInv; else x -= colv[r] * pvInv * rowv[j];
-                }
-            }
-        }
-    }
-}
-
 template<class M>
 __global__ __launch_bounds__(64) void schur_kernel(Buffers bf, int N, int B, float dt)
 {
@@ -463,7 +507,9 @@ __global__ __launch_bounds__(64) void schur_kernel(Buffers bf, int N, int B, flo
             }
             store_vec<NX, NX>(P + y * BR + NX, row);
         }
-        gj_inverse<NQ, false>(Qq, Qi);
+        gj_inverse<NQ, false>(Qq);
+#pragma unroll
+        for (int i = 0; i < NQ * NQ; i++) Qi[i] = Qq[i];
         float di[NQ];
 #pragma unroll
         for (int i = 0; i < NQ; i++) di[i] = 1.0f * (1.0f / Qd[i]);
@@ -495,36 +541,13 @@ __global__ __launch_bounds__(64) void schur_kernel(Buffers bf, int N, int B, flo
         return;
     }
 
-    // ---- k <= N-2
+    // ---- k <= N-2: (Q_k + rho I_q)^-1, (Q_{k+1} + rho I_q)^-1 and R_k^-1 were produced by the assembly kernel's cost wave
     float Qi[NQ * NQ], Qi1[NQ * NQ], di[NQ], di1[NQ], ri[NU];
-    {
-        float Qq[NQ * NQ], Qd[NQ];
-        load_vec<NQ * NQ, NQ * NQ>(Qq, bf.Qq + bk * NQ * NQ);
-        load_vec<NQ, NQ>(Qd, bf.Qd + bk * NQ);
-#pragma unroll
-        for (int i = 0; i < NQ; i++) Qq[i * NQ + i] += rho;
-        gj_inverse<NQ, true>(Qq, Qi);
-#pragma unroll
-        for (int i = 0; i < NQ; i++) di[i] = 1.0f / Qd[i];
-        load_vec<NQ * NQ, NQ * NQ>(Qq, bf.Qq + (bk + 1) * NQ * NQ);
-        load_vec<NQ, NQ>(Qd, bf.Qd + (bk + 1) * NQ);
-#pragma unroll
-        for (int i = 0; i < NQ; i++) Qq[i * NQ + i] += rho;
-        gj_inverse<NQ, true>(Qq, Qi1);
-#pragma unroll
-        for (int i = 0; i < NQ; i++) di1[i] = 1.0f / Qd[i];
-        float Rd[NU];
-        load_vec<NU, NU>(Rd, bf.Rd + bk * NU);
-#pragma unroll
-        for (int i = 0; i < NU; i++) ri[i] = 1.0f / Rd[i];
-    }
-    store_vec<NQ * NQ, NQ * NQ>(bf.Qqi + bk * NQ * NQ, Qi);
-    store_vec<NQ, NQ>(bf.Qdi + bk * NQ, di);
-    store_vec<NU, NU>(bf.Rdi + bk * NU, ri);
-    if (k == N - 2) {
-        store_vec<NQ * NQ, NQ * NQ>(bf.Qqi + (bk + 1) * NQ * NQ, Qi1);
-        store_vec<NQ, NQ>(bf.Qdi + (bk + 1) * NQ, di1);
-    }
+    load_vec<NQ * NQ, NQ * NQ>(Qi, bf.Qqi + bk * NQ * NQ);
+    load_vec<NQ, NQ>(di, bf.Qdi + bk * NQ);
+    load_vec<NQ * NQ, NQ * NQ>(Qi1, bf.Qqi + (bk + 1) * NQ * NQ);
+    load_vec<NQ, NQ>(di1, bf.Qdi + (bk + 1) * NQ);
+    load_vec<NU, NU>(ri, bf.Rdi + bk * NU);
 
     float Dm[3 * NQ * NQ];
     load_vec<3 * NQ * NQ, 3 * NQ * NQ>(Dm, bf.D + bk * 3 * NQ * NQ);
@@ -617,14 +640,14 @@ __global__ __launch_bounds__(64) void schur_kernel(Buffers bf, int N, int B, flo
     }
     // P^-1 main diagonal block of row k+1 = -(theta + rho I_q)^-1
     {
-        float V[NX * NX], W[NX * NX];
+        float W[NX * NX];
 #pragma unroll
         for (int y = 0; y < NX; y++)
 #pragma unroll
-            for (int x = 0; x < NX; x++) V[x * NX + y] = theta[y][x];
+            for (int x = 0; x < NX; x++) W[x * NX + y] = theta[y][x];
 #pragma unroll
-        for (int i = 0; i < NQ; i++) V[i * NX + i] += rho;
-        gj_inverse<NX, false>(V, W);
+        for (int i = 0; i < NQ; i++) W[i * NX + i] += rho;
+        gj_inverse<NX, false>(W);
         float* Pk1 = P + (size_t)(k + 1) * BROW;
 #pragma unroll
         for (int y = 0; y < NX; y++) {

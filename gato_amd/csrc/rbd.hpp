@@ -437,6 +437,42 @@ struct RBD {
         grad_bwd<J, NQ - 1>(f, dfq, dfd, dc_dq[J], dc_dqd[J]);
         if constexpr (J + 1 < NQ) rnea_grad_cols<J + 1>(qd, v, a, f, Iv, dc_dq, dc_dqd);
     }
+    // one derivative column only (the column-split KKT kernel: a wavefront works on ONE J for 64 knots)
+    template<int J> GATO_DEV void rnea_grad_col(const float* qd, const float (*v)[6], const float (*a)[6], const float (*f)[6],
+                                                const float (*Iv)[6], float* dcq, float* dcd) const
+    {
+        float dvq[6], daq[6], dvd[6], dad[6], dfq[NQ][6], dfd[NQ][6];
+        grad_fwd<J, J>(qd, v, a, Iv, dvq, daq, dvd, dad, dfq, dfd);
+        grad_bwd<J, NQ - 1>(f, dfq, dfd, dcq, dcd);
+    }
+    // column J of [dqdd/dq | dqdd/dqd | M^-1]: the three nq-vectors D[J], D[nq+J], D[2nq+J] of the compact KKT storage
+    // `after_qdd(qdd)` runs as soon as the accelerations are known (the defect c_{k+1} is formed there by the J = 0 wave)
+    template<int J, class F> GATO_DEV void fd_grad_column(const float* qd, const float* u, const float* fext, float* colq, float* cold,
+                                                          float* colm, F&& after_qdd) const
+    {
+        MinvT Mi;
+        minv(Mi);
+        float v[NQ][6], a[NQ][6], f[NQ][6], Iv[NQ][6], qdd[NQ];
+        rnea(qd, nullptr, fext, v, a, f);
+        fd_finish(Mi, u, f, qdd);
+        after_qdd(qdd);
+        rnea(qd, qdd, fext, v, a, f);
+        all_Iv<0>(v, Iv);
+        float dcq[NQ], dcd[NQ];
+        rnea_grad_col<J>(qd, v, a, f, Iv, dcq, dcd);
+#pragma unroll
+        for (int r = 0; r < NQ; r++) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int c = 0; c < NQ; c++) {
+                s1 += Mi.sym(r, c) * dcq[c];
+                s2 += Mi.sym(r, c) * dcd[c];
+            }
+            colq[r] = -s1;
+            cold[r] = -s2;
+            colm[r] = Mi.sym(r, J);
+        }
+    }
     template<int K> GATO_DEV void all_Iv(const float (*v)[6], float (*Iv)[6]) const
     {
         Imul<K>(v[K], Iv[K]);

@@ -161,7 +161,7 @@ template<class M> static void launch_merit(GatoSolver* s, hipStream_t st, int na
 }
 template<class M> static void launch_kkt(GatoSolver* s, hipStream_t st, float dt)
 {
-    hipLaunchKernelGGL((kkt_kernel<M>), dim3(cdiv((long)s->B * s->N, 64)), dim3(64), 0, st, s->bf, s->cw, s->N, s->B, dt);
+    hipLaunchKernelGGL((kkt_kernel<M>), dim3(cdiv((long)s->B * s->N, 64), s->nq + 1), dim3(64), 0, st, s->bf, s->cw, s->N, s->B, dt);
 }
 template<class M> static void launch_schur(GatoSolver* s, hipStream_t st, float dt)
 {
@@ -170,7 +170,7 @@ template<class M> static void launch_schur(GatoSolver* s, hipStream_t st, float 
 }
 static int g_pcg_variant = -1;  // test / tuning override (GATO_PCG_VARIANT): 0 strided rows, 1 RPT=6, 2 RPT=3, 3 RPT=2
 
-template<class M, int RPT> static bool try_pcgc(GatoSolver* s, hipStream_t st, int sqp_iter, size_t lds)
+template<class M, int RPT, int FORCE_WPS = 0> static bool try_pcgc(GatoSolver* s, hipStream_t st, int sqp_iter, size_t lds)
 {
     constexpr int NX = 2 * M::NQ;
     if constexpr (NX % RPT != 0) {
@@ -179,7 +179,7 @@ template<class M, int RPT> static bool try_pcgc(GatoSolver* s, hipStream_t st, i
         const int rows = s->N * s->nx;
         const int T = (((rows + RPT - 1) / RPT + 63) / 64) * 64;
         constexpr int REGS = RPT * 6 * NX + 48;            // matrix rows + working set, per lane
-        constexpr int WPS = REGS > 256 ? 1 : (REGS > 168 ? 2 : (REGS > 128 ? 3 : 4));
+        constexpr int WPS = FORCE_WPS ? FORCE_WPS : (REGS > 256 ? 1 : (REGS > 168 ? 2 : (REGS > 128 ? 3 : 4)));
         constexpr int MAXT = WPS * 256;                    // threads per block that still leave REGS registers per lane
         if (T > MAXT) return false;
         hipLaunchKernelGGL((pcgc_kernel<M, RPT, MAXT>), dim3(s->B), dim3(T), lds, st, s->bf, s->N, s->B, s->p.max_pcg_iters, sqp_iter);
@@ -199,6 +199,8 @@ template<class M> static void launch_pcg(GatoSolver* s, hipStream_t st, int sqp_
     // register-resident, contiguous rows: the fewest waves per trajectory that fit the register file
     // measured at indy7 N=32 B=1024 (profiles/r01b_pcg_variants.txt): 2 rows/thread 170 us, 3 rows 184 us, 6 rows (one wave per
     // trajectory) 254 us, strided one row per thread 280 us per launch
+    if (v == 4 && try_pcgc<M, 2, 3>(s, st, sqp_iter, lds)) return;
+    if (v == 5 && try_pcgc<M, 3, 2>(s, st, sqp_iter, lds)) return;  // 3 rows/thread in 256 registers: 4 trajectories (2 waves each) per CU  // 2 rows/thread squeezed into 168 registers: 4 trajectories per CU
     if ((v == 100 || v == 3) && try_pcgc<M, 2>(s, st, sqp_iter, lds)) return;
     if ((v == 100 || v == 2) && try_pcgc<M, 3>(s, st, sqp_iter, lds)) return;
     if ((v == 100 || v == 1) && try_pcgc<M, 6>(s, st, sqp_iter, lds)) return;

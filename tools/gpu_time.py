@@ -33,3 +33,5 @@ print(a.plant, "N", a.N, "B", a.B, "iters", out["iters_done"], "ls", out["ls_num
 print("sqp_time_us:", ["%.0f" % t for t in ts], " -> traj-iter/s %.3e" % (a.B * out["iters_done"] / (min(ts) * 1e-6)))
 print("stage us:", {k: round(v, 1) for k, v in st.items()})
 print("merit", out["initial_merit"][:3], "->", out["final_merit"][:3])
+pi = out["pcg_iters_all"]
+print("pcg iters per SQP iteration: mean", pi.mean(axis=1).round(1), "max", pi.max(axis=1))
