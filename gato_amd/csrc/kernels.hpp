@@ -638,24 +638,39 @@ __global__ __launch_bounds__(64) void schur_kernel(Buffers bf, int N, int B, flo
             store_vec<NX, NX>(Sk + y * BR + 2 * NX, rt);
         }
     }
-    // P^-1 main diagonal block of row k+1 = -(theta + rho I_q)^-1
-    {
-        float W[NX * NX];
+}
+
+// P^-1 main diagonal blocks (schur_linsys.cuh:150-164): row k+1 = -(theta_k + rho I_q)^-1 by the 1-matrix Gauss-Jordan.  Its own
+// launch: theta_k is read back from S (row k+1 main = -theta_k, an exact negation), so the 12 k-instruction chain of the fused form
+// becomes two chains of ~5 k and ~2.5 k instructions that each fit a wavefront's registers far better.  One lane per (b, k >= 1).
+template<class M>
+__global__ __launch_bounds__(64) void pinv_kernel(Buffers bf, int N, int B)
+{
+    constexpr int NQ = M::NQ, NX = 2 * NQ, BR = 3 * NX, BROW = 3 * NX * NX;
+    if (bf.ctrl->done) return;
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    const int k = g % N, b = g / N;
+    if (b >= B || k == 0) return;
+    const float rho = bf.rho[b];
+    const float* Sk = bf.S + ((size_t)b * N + k) * BROW;
+    float* Pk = bf.Pinv + ((size_t)b * N + k) * BROW;
+    float W[NX * NX];
 #pragma unroll
-        for (int y = 0; y < NX; y++)
+    for (int y = 0; y < NX; y++) {
+        float row[NX];
+        load_vec<NX, NX>(row, Sk + y * BR + NX);
 #pragma unroll
-            for (int x = 0; x < NX; x++) W[x * NX + y] = theta[y][x];
+        for (int x = 0; x < NX; x++) W[x * NX + y] = -row[x];
+    }
 #pragma unroll
-        for (int i = 0; i < NQ; i++) W[i * NX + i] += rho;
-        gj_inverse<NX, false>(W);
-        float* Pk1 = P + (size_t)(k + 1) * BROW;
+    for (int i = 0; i < NQ; i++) W[i * NX + i] += rho;
+    gj_inverse<NX, false>(W);
 #pragma unroll
-        for (int y = 0; y < NX; y++) {
-            float row[NX];
+    for (int y = 0; y < NX; y++) {
+        float row[NX];
 #pragma unroll
-            for (int x = 0; x < NX; x++) row[x] = -W[x * NX + y];
-            store_vec<NX, NX>(Pk1 + y * BR + NX, row);
-        }
+        for (int x = 0; x < NX; x++) row[x] = -W[x * NX + y];
+        store_vec<NX, NX>(Pk + y * BR + NX, row);
     }
 }
 
@@ -949,8 +964,12 @@ template<int NXT, int RPT> GATO_DEV void rows_dot(const float (*rows)[3 * NXT], 
     }
 }
 
-template<class M, int RPT, int MAXT>
-__global__ __launch_bounds__(MAXT) void pcgc_kernel(Buffers bf, int N, int B, uint32_t max_iters, int sqp_iter)
+// FOLD: the stair off-diagonals of P^-1 (formSchurSystemBatchedKernel2, schur_linsys.cuh:213-260) are formed HERE, from the stored
+// diagonal blocks, instead of by a kernel of their own: the workgroup holds every block row of the trajectory, so
+// left_k = -Pm_k (phi_{k-1} Pm_{k-1}) and right_k = left_{k+1}^T go through two LDS buffers of N nx^2 floats and straight into the
+// threads' P^-1 rows -- they never touch HBM (write_p != 0 stores them for the stage tests).
+template<class M, int RPT, int MAXT, bool FOLD>
+__global__ __launch_bounds__(MAXT) void pcgc_kernel(Buffers bf, int N, int B, uint32_t max_iters, int sqp_iter, int write_p)
 {
     constexpr int NQ = M::NQ, NX = 2 * NQ, BR = 3 * NX, BROW = 3 * NX * NX;
     static_assert(NX % RPT == 0, "rows of one thread must share a block row");
@@ -986,6 +1005,74 @@ __global__ __launch_bounds__(MAXT) void pcgc_kernel(Buffers bf, int N, int B, ui
             }
             load_vec<RPT, RPT>(xv, lam + NX + rr);
             load_vec<RPT, RPT>(gv, gam + NX + rr);
+        }
+        if constexpr (FOLD) {
+            float* bufA = partB + 16;              // [N][NX][NX]: Pm blocks, later the left blocks
+            float* bufB = bufA + N * NX * NX;      // [N][NX][NX]: phi_{k-1} Pm_{k-1}
+            const int i0 = rr - kb * NX;
+            if (have) {
+#pragma unroll
+                for (int u = 0; u < RPT; u++) store_vec<NX, 2>(bufA + (kb * NX + i0 + u) * NX, &Prow[u][NX]);
+            }
+            __syncthreads();
+            if (have && kb >= 1) {
+                const float* Pm1 = bufA + (kb - 1) * NX * NX;
+#pragma unroll
+                for (int u = 0; u < RPT; u++) {
+                    float scr[NX];
+#pragma unroll
+                    for (int x = 0; x < NX; x++) scr[x] = 0.f;
+#pragma unroll
+                    for (int jj = 0; jj < NX; jj++) {
+                        float prow_[NX];
+                        load_vec<NX, 2>(prow_, Pm1 + jj * NX);
+#pragma unroll
+                        for (int x = 0; x < NX; x++) scr[x] += Srow[u][jj] * prow_[x];
+                    }
+                    store_vec<NX, 2>(bufB + (kb * NX + i0 + u) * NX, scr);
+                }
+            }
+            __syncthreads();
+            if (have) {
+                const float* sc = bufB + kb * NX * NX;
+#pragma unroll
+                for (int u = 0; u < RPT; u++) {
+                    float res[NX];
+#pragma unroll
+                    for (int x = 0; x < NX; x++) res[x] = 0.f;
+                    if (kb >= 1) {
+#pragma unroll
+                        for (int jj = 0; jj < NX; jj++) {
+                            float srow_[NX];
+                            load_vec<NX, 2>(srow_, sc + jj * NX);
+#pragma unroll
+                            for (int x = 0; x < NX; x++) res[x] += Prow[u][NX + jj] * srow_[x];
+                        }
+#pragma unroll
+                        for (int x = 0; x < NX; x++) res[x] = -res[x];
+                    }
+#pragma unroll
+                    for (int x = 0; x < NX; x++) Prow[u][x] = res[x];
+                    store_vec<NX, 2>(bufA + (kb * NX + i0 + u) * NX, res);
+                }
+            }
+            __syncthreads();
+            if (have) {
+#pragma unroll
+                for (int u = 0; u < RPT; u++) {
+#pragma unroll
+                    for (int x = 0; x < NX; x++)
+                        Prow[u][2 * NX + x] = (kb + 1 < N) ? bufA[((kb + 1) * NX + x) * NX + i0 + u] : 0.f;  // right = left_{k+1}^T
+                }
+                if (write_p) {
+                    float* Pg = bf.Pinv + (size_t)b * N * BROW + (size_t)rr * BR;
+#pragma unroll
+                    for (int u = 0; u < RPT; u++) {
+                        store_vec<NX, 2>(Pg + u * BR, &Prow[u][0]);
+                        store_vec<NX, 2>(Pg + u * BR + 2 * NX, &Prow[u][2 * NX]);
+                    }
+                }
+            }
         }
         const float* wa = va + kb * NX;
         const float* wb = vb + kb * NX;

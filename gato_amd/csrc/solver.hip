@@ -163,14 +163,20 @@ template<class M> static void launch_kkt(GatoSolver* s, hipStream_t st, float dt
 {
     hipLaunchKernelGGL((kkt_kernel<M>), dim3(cdiv((long)s->B * s->N, 64), s->nq + 1), dim3(64), 0, st, s->bf, s->cw, s->N, s->B, dt);
 }
-template<class M> static void launch_schur(GatoSolver* s, hipStream_t st, float dt)
+template<class M> static bool pcg_folds_stair(const GatoSolver* s);
+template<class M> static void launch_schur(GatoSolver* s, hipStream_t st, float dt, bool force_stair = false)
 {
-    hipLaunchKernelGGL((schur_kernel<M>), dim3(cdiv((long)s->B * s->N, 64)), dim3(64), 0, st, s->bf, s->N, s->B, dt);
-    hipLaunchKernelGGL((schur2_kernel<M>), dim3(cdiv((long)s->B * s->N, 64)), dim3(64), 0, st, s->bf, s->N, s->B);
+    // A 16-lanes-per-problem cooperative variant of these kernels (lane = column of phi / theta / the Gauss-Jordan tableau, inputs staged
+    // in LDS, pivot columns by ds_bpermute) was built and measured in round 1: bit-compatible, but 2.6 k instructions per lane x 8192
+    // wavefronts = 5x the wave-instructions of the lane-per-problem form and 90 us vs 70 us at C2 -- removed again.
+    const long probs = (long)s->B * s->N;
+    hipLaunchKernelGGL((schur_kernel<M>), dim3(cdiv(probs, 64)), dim3(64), 0, st, s->bf, s->N, s->B, dt);
+    hipLaunchKernelGGL((pinv_kernel<M>), dim3(cdiv(probs, 64)), dim3(64), 0, st, s->bf, s->N, s->B);
+    if (force_stair || !pcg_folds_stair<M>(s)) hipLaunchKernelGGL((schur2_kernel<M>), dim3(cdiv(probs, 64)), dim3(64), 0, st, s->bf, s->N, s->B);
 }
 static int g_pcg_variant = -1;  // test / tuning override (GATO_PCG_VARIANT): 0 strided rows, 1 RPT=6, 2 RPT=3, 3 RPT=2
 
-template<class M, int RPT, int FORCE_WPS = 0> static bool try_pcgc(GatoSolver* s, hipStream_t st, int sqp_iter, size_t lds)
+template<class M, int RPT, int FORCE_WPS = 0> static bool try_pcgc(GatoSolver* s, hipStream_t st, int sqp_iter, size_t lds, bool fold, int write_p)
 {
     constexpr int NX = 2 * M::NQ;
     if constexpr (NX % RPT != 0) {
@@ -182,13 +188,32 @@ template<class M, int RPT, int FORCE_WPS = 0> static bool try_pcgc(GatoSolver* s
         constexpr int WPS = FORCE_WPS ? FORCE_WPS : (REGS > 256 ? 1 : (REGS > 168 ? 2 : (REGS > 128 ? 3 : 4)));
         constexpr int MAXT = WPS * 256;                    // threads per block that still leave REGS registers per lane
         if (T > MAXT) return false;
-        hipLaunchKernelGGL((pcgc_kernel<M, RPT, MAXT>), dim3(s->B), dim3(T), lds, st, s->bf, s->N, s->B, s->p.max_pcg_iters, sqp_iter);
+        if (fold)
+            hipLaunchKernelGGL((pcgc_kernel<M, RPT, MAXT, true>), dim3(s->B), dim3(T), lds + (size_t)2 * s->N * NX * NX * sizeof(float), st, s->bf,
+                               s->N, s->B, s->p.max_pcg_iters, sqp_iter, write_p);
+        else
+            hipLaunchKernelGGL((pcgc_kernel<M, RPT, MAXT, false>), dim3(s->B), dim3(T), lds, st, s->bf, s->N, s->B, s->p.max_pcg_iters, sqp_iter, 0);
         return true;
     }
 }
 
-template<class M> static void launch_pcg(GatoSolver* s, hipStream_t st, int sqp_iter)
+// true when the PCG kernel that will run forms the stair off-diagonals itself (then schur2_kernel is not launched)
+template<class M> static bool pcg_folds_stair(const GatoSolver* s)
 {
+    constexpr int NX = 2 * M::NQ;
+    const char* e = getenv("GATO_PCG_FOLD");
+    if (e && atoi(e) == 0) return false;
+    const char* v = getenv("GATO_PCG_VARIANT");
+    if (v && atoi(v) == 0) return false;
+    const int rows = s->N * s->nx;
+    const bool regs_kernel = (NX % 2 == 0 && ((rows + 1) / 2 + 63) / 64 * 64 <= 512) || (NX % 3 == 0 && ((rows + 2) / 3 + 63) / 64 * 64 <= 256) ||
+                             (NX % 6 == 0 && ((rows + 5) / 6 + 63) / 64 * 64 <= 256);
+    return regs_kernel && (size_t)2 * s->N * NX * NX * sizeof(float) <= 56 * 1024;  // stays under the 64 KB default dynamic-LDS limit
+}
+
+template<class M> static void launch_pcg(GatoSolver* s, hipStream_t st, int sqp_iter, int write_p = 0)
+{
+    const bool fold = pcg_folds_stair<M>(s);
     const int rows = s->N * s->nx;
     const size_t lds = (size_t)(2 * s->vecp + 36) * sizeof(float);
     if (g_pcg_variant < 0) {
@@ -199,11 +224,11 @@ template<class M> static void launch_pcg(GatoSolver* s, hipStream_t st, int sqp_
     // register-resident, contiguous rows: the fewest waves per trajectory that fit the register file
     // measured at indy7 N=32 B=1024 (profiles/r01b_pcg_variants.txt): 2 rows/thread 170 us, 3 rows 184 us, 6 rows (one wave per
     // trajectory) 254 us, strided one row per thread 280 us per launch
-    if (v == 4 && try_pcgc<M, 2, 3>(s, st, sqp_iter, lds)) return;
-    if (v == 5 && try_pcgc<M, 3, 2>(s, st, sqp_iter, lds)) return;  // 3 rows/thread in 256 registers: 4 trajectories (2 waves each) per CU  // 2 rows/thread squeezed into 168 registers: 4 trajectories per CU
-    if ((v == 100 || v == 3) && try_pcgc<M, 2>(s, st, sqp_iter, lds)) return;
-    if ((v == 100 || v == 2) && try_pcgc<M, 3>(s, st, sqp_iter, lds)) return;
-    if ((v == 100 || v == 1) && try_pcgc<M, 6>(s, st, sqp_iter, lds)) return;
+    if (v == 4 && try_pcgc<M, 2, 3>(s, st, sqp_iter, lds, fold, write_p)) return;
+    if (v == 5 && try_pcgc<M, 3, 2>(s, st, sqp_iter, lds, fold, write_p)) return;  // 3 rows/thread in 256 registers
+    if ((v == 100 || v == 3) && try_pcgc<M, 2>(s, st, sqp_iter, lds, fold, write_p)) return;
+    if ((v == 100 || v == 2) && try_pcgc<M, 3>(s, st, sqp_iter, lds, fold, write_p)) return;
+    if ((v == 100 || v == 1) && try_pcgc<M, 6>(s, st, sqp_iter, lds, fold, write_p)) return;
     const int T1 = ((rows + 63) / 64) * 64;
     if (T1 <= 512) {
         hipLaunchKernelGGL((pcg_kernel<M, 1, false, 512>), dim3(s->B), dim3(T1), lds, st, s->bf, s->N, s->B, s->p.max_pcg_iters, sqp_iter);
@@ -586,8 +611,8 @@ template<class M> static int stage_impl(GatoSolver* s, int stage, float dt, floa
     switch (stage) {
         case 0: launch_merit<M>(s, st, NUM_ALPHAS, dt, 1, 0, bf.merit); break;
         case 1: launch_kkt<M>(s, st, dt); break;
-        case 2: launch_schur<M>(s, st, dt); break;
-        case 3: launch_pcg<M>(s, st, 0); break;
+        case 2: launch_schur<M>(s, st, dt, true); break;   // stage tests read the complete P^-1
+        case 3: launch_pcg<M>(s, st, 0, 1); break;
         case 4: launch_dz<M>(s, st, dt, 0); break;
         case 5: launch_ls(s, st, 0); break;
         case 6: launch_merit<M>(s, st, 1, dt, 0, -1, bf.merit_cur); break;
