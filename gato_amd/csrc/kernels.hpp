@@ -108,6 +108,47 @@ GATO_DEV float joint_barrier_hess(float q, float lo, float hi)
     return 1.0f / (amin * amin) + 1.0f / (amax * amax);
 }
 
+// vectorised private<->global copies.  ALIGN = a number of floats that divides every offset the pointer can take (and the
+// allocation itself is 256-byte aligned), so the widest access that is BOTH naturally aligned and divides CNT is used.
+template<int CNT, int ALIGN> constexpr int vec_width()
+{
+    return (CNT % 4 == 0 && ALIGN % 4 == 0) ? 4 : ((CNT % 2 == 0 && ALIGN % 2 == 0) ? 2 : 1);
+}
+template<int CNT, int ALIGN> GATO_DEV void store_vec(float* __restrict__ dst, const float* src)
+{
+    constexpr int W = vec_width<CNT, ALIGN>();
+    if constexpr (W == 4) {
+#pragma unroll
+        for (int i = 0; i < CNT / 4; i++) reinterpret_cast<float4*>(dst)[i] = make_float4(src[4 * i], src[4 * i + 1], src[4 * i + 2], src[4 * i + 3]);
+    } else if constexpr (W == 2) {
+#pragma unroll
+        for (int i = 0; i < CNT / 2; i++) reinterpret_cast<float2*>(dst)[i] = make_float2(src[2 * i], src[2 * i + 1]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < CNT; i++) dst[i] = src[i];
+    }
+}
+template<int CNT, int ALIGN> GATO_DEV void load_vec(float* dst, const float* __restrict__ src)
+{
+    constexpr int W = vec_width<CNT, ALIGN>();
+    if constexpr (W == 4) {
+#pragma unroll
+        for (int i = 0; i < CNT / 4; i++) {
+            const float4 v = reinterpret_cast<const float4*>(src)[i];
+            dst[4 * i] = v.x; dst[4 * i + 1] = v.y; dst[4 * i + 2] = v.z; dst[4 * i + 3] = v.w;
+        }
+    } else if constexpr (W == 2) {
+#pragma unroll
+        for (int i = 0; i < CNT / 2; i++) {
+            const float2 v = reinterpret_cast<const float2*>(src)[i];
+            dst[2 * i] = v.x; dst[2 * i + 1] = v.y;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < CNT; i++) dst[i] = src[i];
+    }
+}
+
 // sum over aligned groups of `seg` consecutive threads (seg = power of two, <= blockDim); every thread gets the group's sum
 GATO_DEV float seg_sum(float v, int seg, float* lds_part)
 {
@@ -150,13 +191,24 @@ __global__ __launch_bounds__(256) void merit_kernel(Buffers bf, Costs cw, int N,
     const float* dz = bf.dz + (size_t)b * traj + (size_t)k * KS;
     const bool last = (k == N - 1);
 
+    // [x_k, u_k, x_{k+1}] + alpha [dz...]; the last knot has x only.  Loads are UNCONDITIONAL (a branch around a load makes hipcc wait for
+    // each one separately: 45 % of this kernel's cycles were such waits): last-knot lanes read the previous knot's tail instead, then zero it.
+    constexpr int AL = (KS % 2 == 0) ? 2 : 1;  // knot offsets are multiples of KS floats, TRAJ = KS N - NU has the parity of KS for NU | KS
     float s[2 * NX + NU];
+    {
+        const float* xt = last ? xu - KS : xu;
+        load_vec<NX, AL>(s, xu);
+        load_vec<NX + NU, AL>(s + NX, xt + NX);
+        if (use_dz) {
+            const float* dt_ = last ? dz - KS : dz;
+            float t[2 * NX + NU];
+            load_vec<NX, AL>(t, dz);
+            load_vec<NX + NU, AL>(t + NX, dt_ + NX);
 #pragma unroll
-    for (int i = 0; i < 2 * NX + NU; i++) {
-        const bool in = (i < NX) || !last;
-        float v = in ? xu[i] : 0.f;
-        if (use_dz && in) v += alpha * dz[i];
-        s[i] = v;
+            for (int i = 0; i < 2 * NX + NU; i++) s[i] += alpha * t[i];
+        }
+#pragma unroll
+        for (int i = NX; i < 2 * NX + NU; i++) s[i] = last ? 0.f : s[i];
     }
     const float* ref = bf.ref + (size_t)b * 6 * N + 6 * k;
 
@@ -278,46 +330,6 @@ GATO_DEV void cost_blocks(const RBD<M>& d, const Costs& cw, const float* x, cons
     }
 }
 
-// vectorised private<->global copies.  ALIGN = a number of floats that divides every offset the pointer can take (and the
-// allocation itself is 256-byte aligned), so the widest access that is BOTH naturally aligned and divides CNT is used.
-template<int CNT, int ALIGN> constexpr int vec_width()
-{
-    return (CNT % 4 == 0 && ALIGN % 4 == 0) ? 4 : ((CNT % 2 == 0 && ALIGN % 2 == 0) ? 2 : 1);
-}
-template<int CNT, int ALIGN> GATO_DEV void store_vec(float* __restrict__ dst, const float* src)
-{
-    constexpr int W = vec_width<CNT, ALIGN>();
-    if constexpr (W == 4) {
-#pragma unroll
-        for (int i = 0; i < CNT / 4; i++) reinterpret_cast<float4*>(dst)[i] = make_float4(src[4 * i], src[4 * i + 1], src[4 * i + 2], src[4 * i + 3]);
-    } else if constexpr (W == 2) {
-#pragma unroll
-        for (int i = 0; i < CNT / 2; i++) reinterpret_cast<float2*>(dst)[i] = make_float2(src[2 * i], src[2 * i + 1]);
-    } else {
-#pragma unroll
-        for (int i = 0; i < CNT; i++) dst[i] = src[i];
-    }
-}
-template<int CNT, int ALIGN> GATO_DEV void load_vec(float* dst, const float* __restrict__ src)
-{
-    constexpr int W = vec_width<CNT, ALIGN>();
-    if constexpr (W == 4) {
-#pragma unroll
-        for (int i = 0; i < CNT / 4; i++) {
-            const float4 v = reinterpret_cast<const float4*>(src)[i];
-            dst[4 * i] = v.x; dst[4 * i + 1] = v.y; dst[4 * i + 2] = v.z; dst[4 * i + 3] = v.w;
-        }
-    } else if constexpr (W == 2) {
-#pragma unroll
-        for (int i = 0; i < CNT / 2; i++) {
-            const float2 v = reinterpret_cast<const float2*>(src)[i];
-            dst[2 * i] = v.x; dst[2 * i + 1] = v.y;
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < CNT; i++) dst[i] = src[i];
-    }
-}
 
 // Gauss-Jordan inverse without pivoting, the arithmetic of block::invertMatrix (linalg.cuh:364-519) on [V | I]:
 //   THREE = true : a / p * row   (2-/3-matrix overloads, used for Q_k, Q_{k+1}, R_k)
@@ -353,36 +365,41 @@ template<int n, bool THREE> GATO_DEV void gj_inverse(float* Mat)
     }
 }
 
-// Column-split assembly: grid.y = NQ + 1.  Wavefronts with blockIdx.y = J < NQ compute, for 64 (b,k) problems, forward dynamics and
-// derivative column J (d qdd / d q_J, d qdd / d qd_J, M^-1[:, J]); J = 0 also stores the defect c_{k+1}.  The common prefix (M^-1,
-// two RNEA passes) is recomputed by each of the NQ waves -- 2.3x the instructions of the one-lane-does-all form, but NQ x the
-// wavefronts at half the registers, which is what a chip with 1024 SIMDs needs at B x N = 32768 problems.
-// blockIdx.y = NQ: cost blocks of knot k (and the terminal ones for k = N-2), their inverses (Q_k + rho I_q)^-1, R_k^-1 -- the
+// Column-split assembly.  Wavefronts with blockIdx.y = g < G compute, for 64 (b,k) problems, forward dynamics and the derivative
+// columns of group g (d qdd / d q_J, d qdd / d qd_J, M^-1[:, J]); the group with column 0 also stores the defect c_{k+1}.  The common
+// prefix (M^-1, two RNEA passes, 3.7 k instructions) is recomputed per group; each column adds 1.3 k.
+// blockIdx.y = G: cost blocks of knot k (and the terminal ones for k = N-2), their inverses (Q_k + rho I_q)^-1, R_k^-1 -- the
 // arithmetic of the 3-matrix Gauss-Jordan of schur_linsys.cuh:96 -- and c_0 = x_0 - x_s (lane k = N-1).
-template<class M, int J>
-GATO_DEV void kkt_column(const Buffers& bf, const float* x, const float* fe, size_t bk, float dt)
+// NOT inlined on purpose: with G tasks inlined into one kernel the code object grows past the +-128 KB reach of s_cbranch
+// (325 KB for iiwa14, G = 7) and the compiler's long-branch relaxation produced wrong results on gfx950 / ROCm 7.2 (columns of D
+// corrupted when f_ext != 0; caught by tests/test_gpu_parity.py).  As real functions every task body stays below 64 KB and is
+// reached through s_swappc; x / fe travel through private memory.
+template<class M, int J0, int CNT>
+__device__ __noinline__ void kkt_columns(float* __restrict__ D, float* __restrict__ c_out, const float* x, const float* fe, float dt)
 {
     constexpr int NQ = M::NQ, NX = 2 * NQ, NU = NQ, KS = NX + NU;
     RBD<M> d;
     d.set_q(x);
-    float cq[NQ], cd[NQ], cm[NQ];
-    d.template fd_grad_column<J>(x + NQ, x + NX, fe, cq, cd, cm, [&](const float* qdd) {
-        if constexpr (J == 0) {
-            float c[NX];
+    d.template fd_grad_columns<J0, CNT>(
+        x + NQ, x + NX, fe,
+        [&](int J, const float* cq, const float* cd, const float* cm) {
+            store_vec<NQ, NQ>(D + J * NQ, cq);
+            store_vec<NQ, NQ>(D + NQ * NQ + J * NQ, cd);
+            store_vec<NQ, NQ>(D + 2 * NQ * NQ + J * NQ, cm);
+        },
+        [&](const float* qdd) {
+            if constexpr (J0 == 0) {
+                float c[NX];
 #pragma unroll
-            for (int i = 0; i < NQ; i++) {
-                const float qdn = x[NQ + i] + dt * qdd[i];
-                const float qn = (float)((double)(x[i] + dt * x[NQ + i]) + 0.5 * (double)qdd[i] * (double)dt * (double)dt);
-                c[i] = x[KS + i] - qn;
-                c[NQ + i] = x[KS + NQ + i] - qdn;
+                for (int i = 0; i < NQ; i++) {
+                    const float qdn = x[NQ + i] + dt * qdd[i];
+                    const float qn = (float)((double)(x[i] + dt * x[NQ + i]) + 0.5 * (double)qdd[i] * (double)dt * (double)dt);
+                    c[i] = x[KS + i] - qn;
+                    c[NQ + i] = x[KS + NQ + i] - qdn;
+                }
+                store_vec<NX, NX>(c_out, c);
             }
-            store_vec<NX, NX>(bf.c + (bk + 1) * NX, c);
-        }
-    });
-    float* D = bf.D + bk * 3 * NQ * NQ;
-    store_vec<NQ, NQ>(D + J * NQ, cq);
-    store_vec<NQ, NQ>(D + NQ * NQ + J * NQ, cd);
-    store_vec<NQ, NQ>(D + 2 * NQ * NQ + J * NQ, cm);
+        });
 }
 
 template<class M>
@@ -424,20 +441,40 @@ GATO_DEV void kkt_costs(const Buffers& bf, const Costs& cw, const float* x, cons
     }
 }
 
-template<class M>
+// G = number of column groups (template): grid.y = G + 1, task g < G owns the derivative columns of group g, task G the cost blocks.
+// The host picks G so that (G + 1) * B * N / 64 wavefronts roughly cover the chip's 1024 SIMDs: G = NQ for small batches (shortest
+// chain), G = 2 at B x N = 32768 (two 7.6 k-instruction chains instead of six 5 k ones: half the wave-instructions), G = 1 beyond.
+template<int NQ, int G, int g> struct ColGroup {  // contiguous, sizes differ by at most one, larger groups first
+    static constexpr int base = NQ / G, extra = NQ % G;
+    static constexpr int start = g * base + (g < extra ? g : extra);
+    static constexpr int count = base + (g < extra ? 1 : 0);
+};
+template<class M, int G, int g> GATO_DEV void kkt_dispatch(int task, const Buffers& bf, const float* x, const float* fe, size_t bk, float dt)
+{
+    if constexpr (g < G) {
+        if (task == g) {
+            constexpr int NQ = M::NQ;
+            kkt_columns<M, ColGroup<NQ, G, g>::start, ColGroup<NQ, G, g>::count>(bf.D + bk * 3 * NQ * NQ, bf.c + (bk + 1) * 2 * NQ, x, fe, dt);
+        } else {
+            kkt_dispatch<M, G, g + 1>(task, bf, x, fe, bk, dt);
+        }
+    }
+}
+
+template<class M, int G>
 __global__ __launch_bounds__(64) void kkt_kernel(Buffers bf, Costs cw, int N, int B, float dt)
 {
     constexpr int NQ = M::NQ, NX = 2 * NQ, NU = NQ, KS = NX + NU;
     if (bf.ctrl->done) return;
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     const int k = g % N, b = g / N;
-    const int task = blockIdx.y;
+    const int task = blockIdx.y;  // wave-uniform
     if (b >= B) return;
     const int traj = KS * N - NU;
     const float* xu = bf.xu + (size_t)b * traj + (size_t)k * KS;
     const size_t bk = (size_t)b * N + k;
     if (k == N - 1) {
-        if (task == NQ) {
+        if (task == G) {
             float c0[NX];
             const float* x0 = bf.xu + (size_t)b * traj;
 #pragma unroll
@@ -449,23 +486,13 @@ __global__ __launch_bounds__(64) void kkt_kernel(Buffers bf, Costs cw, int N, in
     float x[KS + NX], fe[6];
 #pragma unroll
     for (int i = 0; i < KS + NX; i++) x[i] = xu[i];
-    if (task == NQ) {
+    if (task == G) {
         kkt_costs<M>(bf, cw, x, bf.ref + (size_t)b * 6 * N + 6 * k, bk, bf.rho[b], k == N - 2);
         return;
     }
 #pragma unroll
     for (int i = 0; i < 6; i++) fe[i] = bf.f_ext[6 * b + i];
-    switch (task) {  // wave-uniform
-        case 0: kkt_column<M, 0>(bf, x, fe, bk, dt); break;
-        case 1: kkt_column<M, 1>(bf, x, fe, bk, dt); break;
-        case 2: kkt_column<M, 2>(bf, x, fe, bk, dt); break;
-        case 3: kkt_column<M, 3>(bf, x, fe, bk, dt); break;
-        case 4: kkt_column<M, 4>(bf, x, fe, bk, dt); break;
-        case 5: kkt_column<M, 5>(bf, x, fe, bk, dt); break;
-        default:
-            if constexpr (NQ > 6) kkt_column<M, NQ - 1>(bf, x, fe, bk, dt);
-            break;
-    }
+    kkt_dispatch<M, G, 0>(task, bf, x, fe, bk, dt);
 }
 
 // =========================================================================================================================
@@ -1167,10 +1194,9 @@ __global__ __launch_bounds__(256) void dz_kernel(Buffers bf, int N, int B, float
     float lk[NX], lk1[NX], Dm[3 * NQ * NQ];
     load_vec<NX, NX>(lk, lam + (size_t)(k + 1) * NX);
     const bool inner = k < N - 1;
-    if (inner) {
-        load_vec<NX, NX>(lk1, lam + (size_t)(k + 2) * NX);
-        load_vec<3 * NQ * NQ, 3 * NQ * NQ>(Dm, bf.D + bk * 3 * NQ * NQ);
-    }
+    // unconditional loads (valid memory for the last knot too: lambda's zero padding block, an unused D slot)
+    load_vec<NX, NX>(lk1, lam + (size_t)(k + 2) * NX);
+    load_vec<3 * NQ * NQ, 3 * NQ * NQ>(Dm, bf.D + bk * 3 * NQ * NQ);
     // state row
     {
         float qk[NX], res[NX], Qi[NQ * NQ], di[NQ], out[NX];

@@ -446,9 +446,33 @@ struct RBD {
         grad_bwd<J, NQ - 1>(f, dfq, dfd, dcq, dcd);
     }
     // column J of [dqdd/dq | dqdd/dqd | M^-1]: the three nq-vectors D[J], D[nq+J], D[2nq+J] of the compact KKT storage
-    // `after_qdd(qdd)` runs as soon as the accelerations are known (the defect c_{k+1} is formed there by the J = 0 wave)
-    template<int J, class F> GATO_DEV void fd_grad_column(const float* qd, const float* u, const float* fext, float* colq, float* cold,
-                                                          float* colm, F&& after_qdd) const
+    // Columns J0 .. J0+CNT-1 of [dqdd/dq | dqdd/dqd | M^-1] after ONE evaluation of the common prefix (M^-1, RNEA, qdd, RNEA at qdd):
+    // `emit(J, colq, cold, colm)` receives each column, `after_qdd(qdd)` runs as soon as the accelerations are known (the defect
+    // c_{k+1} is formed there by the task that owns column 0).
+    template<int J, int JEND, class E> GATO_DEV void grad_columns_loop(const float* qd, const float (*v)[6], const float (*a)[6],
+                                                                       const float (*f)[6], const float (*Iv)[6], const MinvT& Mi, E&& emit) const
+    {
+        if constexpr (J < JEND) {
+            float dcq[NQ], dcd[NQ], colq[NQ], cold[NQ], colm[NQ];
+            rnea_grad_col<J>(qd, v, a, f, Iv, dcq, dcd);
+#pragma unroll
+            for (int r = 0; r < NQ; r++) {
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int c = 0; c < NQ; c++) {
+                    s1 += Mi.sym(r, c) * dcq[c];
+                    s2 += Mi.sym(r, c) * dcd[c];
+                }
+                colq[r] = -s1;
+                cold[r] = -s2;
+                colm[r] = Mi.sym(r, J);
+            }
+            emit(J, colq, cold, colm);
+            grad_columns_loop<J + 1, JEND>(qd, v, a, f, Iv, Mi, emit);
+        }
+    }
+    template<int J0, int CNT, class E, class F> GATO_DEV void fd_grad_columns(const float* qd, const float* u, const float* fext, E&& emit,
+                                                                              F&& after_qdd) const
     {
         MinvT Mi;
         minv(Mi);
@@ -458,20 +482,7 @@ struct RBD {
         after_qdd(qdd);
         rnea(qd, qdd, fext, v, a, f);
         all_Iv<0>(v, Iv);
-        float dcq[NQ], dcd[NQ];
-        rnea_grad_col<J>(qd, v, a, f, Iv, dcq, dcd);
-#pragma unroll
-        for (int r = 0; r < NQ; r++) {
-            float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-            for (int c = 0; c < NQ; c++) {
-                s1 += Mi.sym(r, c) * dcq[c];
-                s2 += Mi.sym(r, c) * dcd[c];
-            }
-            colq[r] = -s1;
-            cold[r] = -s2;
-            colm[r] = Mi.sym(r, J);
-        }
+        grad_columns_loop<J0, J0 + CNT>(qd, v, a, f, Iv, Mi, emit);
     }
     template<int K> GATO_DEV void all_Iv(const float (*v)[6], float (*Iv)[6]) const
     {
