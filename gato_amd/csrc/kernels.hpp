@@ -1028,7 +1028,8 @@ __global__ __launch_bounds__(MAXT) void pcgc_kernel(Buffers bf, int N, int B, ui
 #pragma unroll
             for (int u = 0; u < RPT; u++) {
                 load_vec<BR, NX>(Srow[u], S + u * BR);
-                load_vec<BR, NX>(Prow[u], P + u * BR);
+                if constexpr (FOLD) load_vec<NX, NX>(&Prow[u][NX], P + u * BR + NX);  // off-diagonals are formed below
+                else load_vec<BR, NX>(Prow[u], P + u * BR);
             }
             load_vec<RPT, RPT>(xv, lam + NX + rr);
             load_vec<RPT, RPT>(gv, gam + NX + rr);

@@ -211,7 +211,7 @@ template<class M> static bool pcg_folds_stair(const GatoSolver* s)
     if (v && atoi(v) == 0) return false;
     const int rows = s->N * s->nx;
     const bool regs_kernel = (NX % 2 == 0 && ((rows + 1) / 2 + 63) / 64 * 64 <= 512) || (NX % 3 == 0 && ((rows + 2) / 3 + 63) / 64 * 64 <= 256) ||
-                             (NX % 6 == 0 && ((rows + 5) / 6 + 63) / 64 * 64 <= 256);
+                             (NX % 6 == 0 && ((rows + 5) / 6 + 63) / 64 * 64 <= 256) || (v && atoi(v) == 6);
     return regs_kernel && (size_t)2 * s->N * NX * NX * sizeof(float) <= 56 * 1024;  // stays under the 64 KB default dynamic-LDS limit
 }
 
@@ -229,6 +229,7 @@ template<class M> static void launch_pcg(GatoSolver* s, hipStream_t st, int sqp_
     // measured at indy7 N=32 B=1024 (profiles/r01b_pcg_variants.txt): 2 rows/thread 170 us, 3 rows 184 us, 6 rows (one wave per
     // trajectory) 254 us, strided one row per thread 280 us per launch
     if (v == 4 && try_pcgc<M, 2, 3>(s, st, sqp_iter, lds, fold, write_p)) return;
+    if (v == 6 && try_pcgc<M, 1>(s, st, sqp_iter, lds, fold, write_p)) return;     // 1 row/thread, 6 waves per indy7 N=32 trajectory
     if (v == 5 && try_pcgc<M, 3, 2>(s, st, sqp_iter, lds, fold, write_p)) return;  // 3 rows/thread in 256 registers
     if ((v == 100 || v == 3) && try_pcgc<M, 2>(s, st, sqp_iter, lds, fold, write_p)) return;
     if ((v == 100 || v == 2) && try_pcgc<M, 3>(s, st, sqp_iter, lds, fold, write_p)) return;
