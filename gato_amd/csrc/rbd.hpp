@@ -378,16 +378,17 @@ struct RBD {
         }
         // df = I da + dv x* (I v) + v x* (I dv)
         {
-            float Ida[6], Idv[6], t1[6], t2[6];
+            float Ida[6], Idv[6], t1[6], t2[6], Ivl[6];
+            Imul<I2>(v[I2], Ivl);  // recomputed here instead of kept for all bodies: 6 x 6 fewer live registers, same value
             Imul<I2>(daq, Ida);
             Imul<I2>(dvq, Idv);
-            fxv(dvq, Iv[I2], t1);
+            fxv(dvq, Ivl, t1);
             fxv(v[I2], Idv, t2);
 #pragma unroll
             for (int r = 0; r < 6; r++) dfq[I2][r] = Ida[r] + t1[r] + t2[r];
             Imul<I2>(dad, Ida);
             Imul<I2>(dvd, Idv);
-            fxv(dvd, Iv[I2], t1);
+            fxv(dvd, Ivl, t1);
             fxv(v[I2], Idv, t2);
 #pragma unroll
             for (int r = 0; r < 6; r++) dfd[I2][r] = Ida[r] + t1[r] + t2[r];
