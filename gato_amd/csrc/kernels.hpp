@@ -410,8 +410,11 @@ __device__ __noinline__ void kkt_columns(float* __restrict__ D, float* __restric
         });
 }
 
+// Cost blocks of one knot and their inverses (Q + rho I_q)^-1, R^-1 -- the arithmetic of the 3-matrix Gauss-Jordan of
+// schur_linsys.cuh:96.  `terminal`: the lane produces the blocks of knot N-1 from x_{N-2} against ref_{N-1} and
+// has no R block.  One uniform instruction stream for both kinds of lane; only the R stores are predicated.
 template<class M>
-GATO_DEV void kkt_costs(const Buffers& bf, const Costs& cw, const float* x, const float* ref, size_t bk, float rho, bool terminal_too)
+GATO_DEV void kkt_costs(const Buffers& bf, const Costs& cw, const float* x, const float* ref, size_t bk, float rho, bool terminal)
 {
     constexpr int NQ = M::NQ, NX = 2 * NQ, NU = NQ;
     RBD<M> d;
@@ -421,8 +424,10 @@ GATO_DEV void kkt_costs(const Buffers& bf, const Costs& cw, const float* x, cons
     store_vec<NQ * NQ, NQ * NQ>(bf.Qq + bk * NQ * NQ, Qq);
     store_vec<NQ, NQ>(bf.Qd + bk * NQ, Qd);
     store_vec<NX, NX>(bf.q + bk * NX, qv);
-    store_vec<NU, NU>(bf.Rd + bk * NU, Rd);
-    store_vec<NU, NU>(bf.r + bk * NU, rv);
+    if (!terminal) {
+        store_vec<NU, NU>(bf.Rd + bk * NU, Rd);
+        store_vec<NU, NU>(bf.r + bk * NU, rv);
+    }
 #pragma unroll
     for (int i = 0; i < NQ; i++) {
         Qq[i * NQ + i] += rho;        // first nx/2 diagonal entries only (linalg.cuh:84-96)
@@ -432,75 +437,47 @@ GATO_DEV void kkt_costs(const Buffers& bf, const Costs& cw, const float* x, cons
     gj_inverse<NQ, true>(Qq);
     store_vec<NQ * NQ, NQ * NQ>(bf.Qqi + bk * NQ * NQ, Qq);
     store_vec<NQ, NQ>(bf.Qdi + bk * NQ, Qd);
-    store_vec<NU, NU>(bf.Rdi + bk * NU, Rd);
-    if (terminal_too) {
-        cost_blocks<M>(d, cw, x, x + NX, ref + 6, Qq, Qd, qv, nullptr, nullptr);
-        store_vec<NQ * NQ, NQ * NQ>(bf.Qq + (bk + 1) * NQ * NQ, Qq);
-        store_vec<NQ, NQ>(bf.Qd + (bk + 1) * NQ, Qd);
-        store_vec<NX, NX>(bf.q + (bk + 1) * NX, qv);
-#pragma unroll
-        for (int i = 0; i < NQ; i++) {
-            Qq[i * NQ + i] += rho;
-            Qd[i] = 1.0f / Qd[i];
-        }
-        gj_inverse<NQ, true>(Qq);
-        store_vec<NQ * NQ, NQ * NQ>(bf.Qqi + (bk + 1) * NQ * NQ, Qq);
-        store_vec<NQ, NQ>(bf.Qdi + (bk + 1) * NQ, Qd);
-    }
+    if (!terminal) store_vec<NU, NU>(bf.Rdi + bk * NU, Rd);
 }
 
-// G = number of column groups (template): grid.y = G + 1, task g < G owns the derivative columns of group g, task G the cost blocks.
-// The host picks G so that (G + 1) * B * N / 64 wavefronts roughly cover the chip's 1024 SIMDs: G = NQ for small batches (shortest
-// chain), G = 2 at B x N = 32768 (two 7.6 k-instruction chains instead of six 5 k ones: half the wave-instructions), G = 1 beyond.
-template<int NQ, int G, int g> struct ColGroup {  // contiguous, sizes differ by at most one, larger groups first
-    static constexpr int base = NQ / G, extra = NQ % G;
-    static constexpr int start = g * base + (g < extra ? g : extra);
-    static constexpr int count = base + (g < extra ? 1 : 0);
-};
-template<class M, int G, int g> GATO_DEV void kkt_dispatch(int task, const Buffers& bf, const float* x, const float* fe, size_t bk, float dt)
-{
-    if constexpr (g < G) {
-        if (task == g) {
-            constexpr int NQ = M::NQ;
-            kkt_columns<M, ColGroup<NQ, G, g>::start, ColGroup<NQ, G, g>::count>(bf.D + bk * 3 * NQ * NQ, bf.c + (bk + 1) * 2 * NQ, x, fe, dt);
-        } else {
-            kkt_dispatch<M, G, g + 1>(task, bf, x, fe, bk, dt);
-        }
-    }
-}
-
-template<class M, int G>
+// Two tasks (grid.y = 2), one wavefront of 64 (b,k) lanes each, the same split for every batch size (results do not depend on B):
+//   task 0: forward dynamics, defect c_{k+1}, derivative columns [0, NQ/2)            (the long columns)
+//   task 1: forward dynamics, derivative columns [NQ/2, NQ), then the cost blocks of knot k; its lane k = N-1 -- idle in the
+//           column part -- produces the terminal blocks from x_{N-2} and c_0 = x_0 - x_s.
+// Both tasks are ~7 k instructions; B x N / 64 x 2 wavefronts is one round on the chip's 1024 SIMDs at C2.
+template<class M>
 __global__ __launch_bounds__(64) void kkt_kernel(Buffers bf, Costs cw, int N, int B, float dt)
 {
-    constexpr int NQ = M::NQ, NX = 2 * NQ, NU = NQ, KS = NX + NU;
+    constexpr int NQ = M::NQ, NX = 2 * NQ, NU = NQ, KS = NX + NU, H = NQ / 2;
     if (bf.ctrl->done) return;
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     const int k = g % N, b = g / N;
     const int task = blockIdx.y;  // wave-uniform
     if (b >= B) return;
+    const bool last = (k == N - 1);
+    if (last && task == 0) return;
     const int traj = KS * N - NU;
-    const float* xu = bf.xu + (size_t)b * traj + (size_t)k * KS;
+    const int kx = last ? N - 2 : k;  // the terminal lane reads knot N-2
+    const float* xu = bf.xu + (size_t)b * traj + (size_t)kx * KS;
     const size_t bk = (size_t)b * N + k;
-    if (k == N - 1) {
-        if (task == G) {
-            float c0[NX];
-            const float* x0 = bf.xu + (size_t)b * traj;
-#pragma unroll
-            for (int i = 0; i < NX; i++) c0[i] = x0[i] - bf.x_s[(size_t)b * NX + i];
-            store_vec<NX, NX>(bf.c + (size_t)b * N * NX, c0);
-        }
-        return;
-    }
     float x[KS + NX], fe[6];
 #pragma unroll
     for (int i = 0; i < KS + NX; i++) x[i] = xu[i];
-    if (task == G) {
-        kkt_costs<M>(bf, cw, x, bf.ref + (size_t)b * 6 * N + 6 * k, bk, bf.rho[b], k == N - 2);
-        return;
-    }
 #pragma unroll
     for (int i = 0; i < 6; i++) fe[i] = bf.f_ext[6 * b + i];
-    kkt_dispatch<M, G, 0>(task, bf, x, fe, bk, dt);
+    if (task == 0) {
+        kkt_columns<M, 0, H>(bf.D + bk * 3 * NQ * NQ, bf.c + (bk + 1) * NX, x, fe, dt);
+        return;
+    }
+    if (!last) kkt_columns<M, H, NQ - H>(bf.D + bk * 3 * NQ * NQ, nullptr, x, fe, dt);
+    kkt_costs<M>(bf, cw, x, bf.ref + (size_t)b * 6 * N + 6 * (last ? N - 1 : k), bk, bf.rho[b], last);
+    if (last) {
+        float c0[NX];
+        const float* x0 = bf.xu + (size_t)b * traj;
+#pragma unroll
+        for (int i = 0; i < NX; i++) c0[i] = x0[i] - bf.x_s[(size_t)b * NX + i];
+        store_vec<NX, NX>(bf.c + (size_t)b * N * NX, c0);
+    }
 }
 
 // =========================================================================================================================

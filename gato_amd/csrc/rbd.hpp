@@ -35,6 +35,14 @@ GATO_DEV void cmad(float& acc, bool& started, const float coef, const float x)
     }
 }
 
+// A wave-uniform `true` the optimiser cannot see through: `if (opaque_true()) { phase }` gives `phase` its own basic block.
+GATO_DEV bool opaque_true()
+{
+    int one;
+    asm volatile("s_mov_b32 %0, 1" : "=s"(one));
+    return one != 0;
+}
+
 template<class M>
 struct RBD {
     static constexpr int NQ = M::NQ;
@@ -332,78 +340,67 @@ struct RBD {
 
     // ---- d(RNEA)/d(q_J) and d(RNEA)/d(qd_J), one derivative column at a time --------------------------------------
     // Same recursions as inverse_dynamics_gradient_inner (indy7_grid.cuh:3373-3774); dc_dq[i], dc_dqd[i] = d c_i / d (q_J, qd_J).
-    template<int J, int I2> GATO_DEV void grad_fwd(const float* qd, const float (*v)[6], const float (*a)[6], const float (*Iv)[6],
-                                                   float* dvq, float* daq, float* dvd, float* dad, float (*dfq)[6], float (*dfd)[6]) const
+    // QD = false: derivatives w.r.t. q_J (dv, da, df hold d/dq_J);  QD = true: w.r.t. qd_J.  The two passes share nothing but v, a, f,
+    // so they run one after the other: together they kept 440 registers live, apart 270 (hipcc 7.2, gfx950).
+    template<int J, int I2, bool QD> GATO_DEV void grad_fwd(const float* qd, const float (*v)[6], const float (*a)[6], float* dv, float* da,
+                                                            float (*df)[6]) const
     {
-        // on entry (I2 > J): dv*, da* hold the derivatives of body I2-1; on exit those of body I2
+        // on entry (I2 > J): dv, da hold the derivatives of body I2-1; on exit those of body I2
         if constexpr (I2 == J) {
-            if constexpr (J == 0) {
+            if constexpr (QD) {
+#pragma unroll
+                for (int r = 0; r < 6; r++) dv[r] = 0.f;
+                dv[2] = 1.f;
+                // da/dqd_J = mx2(S) qd_J + mx2(v_J) = mx2(v_J)   (mx2(S) = 0)
+                mx2(v[J], da);
+            } else if constexpr (J == 0) {
                 const float g6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, G};
                 float Xa[6];
                 X<0>(g6, Xa);
 #pragma unroll
-                for (int r = 0; r < 6; r++) dvq[r] = 0.f;
-                mx2(Xa, daq);
+                for (int r = 0; r < 6; r++) dv[r] = 0.f;
+                mx2(Xa, da);
             } else {
                 float Xv[6], Xa[6], t[6];
                 X<J>(v[J - 1], Xv);
                 X<J>(a[J - 1], Xa);
-                mx2(Xv, dvq);
-                mx2(dvq, t);
-                mx2(Xa, daq);
+                mx2(Xv, dv);
+                mx2(dv, t);
+                mx2(Xa, da);
 #pragma unroll
-                for (int r = 0; r < 6; r++) daq[r] += t[r] * qd[J];
+                for (int r = 0; r < 6; r++) da[r] += t[r] * qd[J];
             }
-#pragma unroll
-            for (int r = 0; r < 6; r++) dvd[r] = 0.f;
-            dvd[2] = 1.f;
-            // da/dqd_J = mx2(S) qd_J + mx2(v_J) = mx2(v_J)   (mx2(S) = 0)
-            mx2(v[J], dad);
         } else {
             float t[6], u6[6];
-            X<I2>(dvq, t);
+            X<I2>(dv, t);
 #pragma unroll
-            for (int r = 0; r < 6; r++) dvq[r] = t[r];
-            X<I2>(daq, t);
-            mx2(dvq, u6);
+            for (int r = 0; r < 6; r++) dv[r] = t[r];
+            X<I2>(da, t);
+            mx2(dv, u6);
 #pragma unroll
-            for (int r = 0; r < 6; r++) daq[r] = t[r] + u6[r] * qd[I2];
-            X<I2>(dvd, t);
-#pragma unroll
-            for (int r = 0; r < 6; r++) dvd[r] = t[r];
-            X<I2>(dad, t);
-            mx2(dvd, u6);
-#pragma unroll
-            for (int r = 0; r < 6; r++) dad[r] = t[r] + u6[r] * qd[I2];
+            for (int r = 0; r < 6; r++) da[r] = t[r] + u6[r] * qd[I2];
         }
         // df = I da + dv x* (I v) + v x* (I dv)
         {
             float Ida[6], Idv[6], t1[6], t2[6], Ivl[6];
-            Imul<I2>(v[I2], Ivl);  // recomputed here instead of kept for all bodies: 6 x 6 fewer live registers, same value
-            Imul<I2>(daq, Ida);
-            Imul<I2>(dvq, Idv);
-            fxv(dvq, Ivl, t1);
+            Imul<I2>(v[I2], Ivl);  // recomputed here instead of kept for all bodies: fewer live registers, same value
+            Imul<I2>(da, Ida);
+            Imul<I2>(dv, Idv);
+            fxv(dv, Ivl, t1);
             fxv(v[I2], Idv, t2);
 #pragma unroll
-            for (int r = 0; r < 6; r++) dfq[I2][r] = Ida[r] + t1[r] + t2[r];
-            Imul<I2>(dad, Ida);
-            Imul<I2>(dvd, Idv);
-            fxv(dvd, Ivl, t1);
-            fxv(v[I2], Idv, t2);
-#pragma unroll
-            for (int r = 0; r < 6; r++) dfd[I2][r] = Ida[r] + t1[r] + t2[r];
+            for (int r = 0; r < 6; r++) df[I2][r] = Ida[r] + t1[r] + t2[r];
         }
-        if constexpr (I2 + 1 < NQ) grad_fwd<J, I2 + 1>(qd, v, a, Iv, dvq, daq, dvd, dad, dfq, dfd);
+        if constexpr (I2 + 1 < NQ) grad_fwd<J, I2 + 1, QD>(qd, v, a, dv, da, df);
     }
-    template<int J, int I2> GATO_DEV void grad_bwd(const float (*f)[6], float (*dfq)[6], float (*dfd)[6], float* dcq, float* dcd) const
+    template<int J, int I2, bool QD> GATO_DEV void grad_bwd(const float (*f)[6], float (*df)[6], float* dc) const
     {
         // I2 runs NQ-1 .. 0; df[I2] is complete when visited.  Bodies below J only receive the propagated part.
-        dcq[I2] = dfq[I2][2];
-        dcd[I2] = dfd[I2][2];
+        dc[I2] = df[I2][2];
         if constexpr (I2 >= 1) {
             float t[6];
-            XT<I2>(dfq[I2], t);
-            if constexpr (I2 == J) {
+            XT<I2>(df[I2], t);
+            if constexpr (I2 == J && !QD) {
                 // + d(X_J^T)/dq_J f_J = -X_J^T mx2(f_J)
                 float mf[6], t2[6];
                 mx2(f[J], mf);
@@ -413,38 +410,37 @@ struct RBD {
             }
             if constexpr (I2 - 1 >= J) {
 #pragma unroll
-                for (int r = 0; r < 6; r++) dfq[I2 - 1][r] += t[r];
+                for (int r = 0; r < 6; r++) df[I2 - 1][r] += t[r];
             } else {
 #pragma unroll
-                for (int r = 0; r < 6; r++) dfq[I2 - 1][r] = t[r];
+                for (int r = 0; r < 6; r++) df[I2 - 1][r] = t[r];
             }
-            XT<I2>(dfd[I2], t);
-            if constexpr (I2 - 1 >= J) {
-#pragma unroll
-                for (int r = 0; r < 6; r++) dfd[I2 - 1][r] += t[r];
-            } else {
-#pragma unroll
-                for (int r = 0; r < 6; r++) dfd[I2 - 1][r] = t[r];
-            }
-            grad_bwd<J, I2 - 1>(f, dfq, dfd, dcq, dcd);
+            grad_bwd<J, I2 - 1, QD>(f, df, dc);
         }
     }
     // dc_dq[J][i] = d c_i / d q_J, dc_dqd[J][i] = d c_i / d qd_J   (v,a,f from rnea() at the solved qdd)
     template<int J> GATO_DEV void rnea_grad_cols(const float* qd, const float (*v)[6], const float (*a)[6], const float (*f)[6],
                                                  const float (*Iv)[6], float (*dc_dq)[NQ], float (*dc_dqd)[NQ]) const
     {
-        float dvq[6], daq[6], dvd[6], dad[6], dfq[NQ][6], dfd[NQ][6];
-        grad_fwd<J, J>(qd, v, a, Iv, dvq, daq, dvd, dad, dfq, dfd);
-        grad_bwd<J, NQ - 1>(f, dfq, dfd, dc_dq[J], dc_dqd[J]);
+        rnea_grad_col<J>(qd, v, a, f, Iv, dc_dq[J], dc_dqd[J]);
         if constexpr (J + 1 < NQ) rnea_grad_cols<J + 1>(qd, v, a, f, Iv, dc_dq, dc_dqd);
     }
     // one derivative column only (the column-split KKT kernel: a wavefront works on ONE J for 64 knots)
     template<int J> GATO_DEV void rnea_grad_col(const float* qd, const float (*v)[6], const float (*a)[6], const float (*f)[6],
                                                 const float (*Iv)[6], float* dcq, float* dcd) const
     {
-        float dvq[6], daq[6], dvd[6], dad[6], dfq[NQ][6], dfd[NQ][6];
-        grad_fwd<J, J>(qd, v, a, Iv, dvq, daq, dvd, dad, dfq, dfd);
-        grad_bwd<J, NQ - 1>(f, dfq, dfd, dcq, dcd);
+        // Each pass in its own basic block (a branch the compiler cannot fold): instruction selection and scheduling work per block,
+        // so the two independent passes are not interleaved for ILP (which kept 440 registers live instead of 270).
+        {
+            float dv[6], da[6], df[NQ][6];
+            if (opaque_true()) grad_fwd<J, J, false>(qd, v, a, dv, da, df);
+            if (opaque_true()) grad_bwd<J, NQ - 1, false>(f, df, dcq);
+        }
+        {
+            float dv[6], da[6], df[NQ][6];
+            if (opaque_true()) grad_fwd<J, J, true>(qd, v, a, dv, da, df);
+            if (opaque_true()) grad_bwd<J, NQ - 1, true>(f, df, dcd);
+        }
     }
     // column J of [dqdd/dq | dqdd/dqd | M^-1]: the three nq-vectors D[J], D[nq+J], D[2nq+J] of the compact KKT storage
     // Columns J0 .. J0+CNT-1 of [dqdd/dq | dqdd/dqd | M^-1] after ONE evaluation of the common prefix (M^-1, RNEA, qdd, RNEA at qdd):
@@ -454,36 +450,41 @@ struct RBD {
                                                                        const float (*f)[6], const float (*Iv)[6], const MinvT& Mi, E&& emit) const
     {
         if constexpr (J < JEND) {
-            float dcq[NQ], dcd[NQ], colq[NQ], cold[NQ], colm[NQ];
+            float dcq[NQ], dcd[NQ];
             rnea_grad_col<J>(qd, v, a, f, Iv, dcq, dcd);
+            if (opaque_true()) {
+                float colq[NQ], cold[NQ], colm[NQ];
 #pragma unroll
-            for (int r = 0; r < NQ; r++) {
-                float s1 = 0.f, s2 = 0.f;
+                for (int r = 0; r < NQ; r++) {
+                    float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-                for (int c = 0; c < NQ; c++) {
-                    s1 += Mi.sym(r, c) * dcq[c];
-                    s2 += Mi.sym(r, c) * dcd[c];
+                    for (int c = 0; c < NQ; c++) {
+                        s1 += Mi.sym(r, c) * dcq[c];
+                        s2 += Mi.sym(r, c) * dcd[c];
+                    }
+                    colq[r] = -s1;
+                    cold[r] = -s2;
+                    colm[r] = Mi.sym(r, J);
                 }
-                colq[r] = -s1;
-                cold[r] = -s2;
-                colm[r] = Mi.sym(r, J);
+                emit(J, colq, cold, colm);
             }
-            emit(J, colq, cold, colm);
             grad_columns_loop<J + 1, JEND>(qd, v, a, f, Iv, Mi, emit);
         }
     }
     template<int J0, int CNT, class E, class F> GATO_DEV void fd_grad_columns(const float* qd, const float* u, const float* fext, E&& emit,
                                                                               F&& after_qdd) const
     {
+        // phases in basic blocks of their own (see rnea_grad_col)
         MinvT Mi;
-        minv(Mi);
-        float v[NQ][6], a[NQ][6], f[NQ][6], Iv[NQ][6], qdd[NQ];
-        rnea(qd, nullptr, fext, v, a, f);
-        fd_finish(Mi, u, f, qdd);
-        after_qdd(qdd);
-        rnea(qd, qdd, fext, v, a, f);
-        all_Iv<0>(v, Iv);
-        grad_columns_loop<J0, J0 + CNT>(qd, v, a, f, Iv, Mi, emit);
+        if (opaque_true()) minv(Mi);
+        float v[NQ][6], a[NQ][6], f[NQ][6], qdd[NQ];
+        if (opaque_true()) {
+            rnea(qd, nullptr, fext, v, a, f);
+            fd_finish(Mi, u, f, qdd);
+            after_qdd(qdd);
+        }
+        if (opaque_true()) rnea(qd, qdd, fext, v, a, f);
+        grad_columns_loop<J0, J0 + CNT>(qd, v, a, f, nullptr, Mi, emit);
     }
     template<int K> GATO_DEV void all_Iv(const float (*v)[6], float (*Iv)[6]) const
     {

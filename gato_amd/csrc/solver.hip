@@ -161,11 +161,9 @@ template<class M> static void launch_merit(GatoSolver* s, hipStream_t st, int na
 }
 template<class M> static void launch_kkt(GatoSolver* s, hipStream_t st, float dt)
 {
-    // Three column groups + the cost task, for EVERY batch size: the grouping changes the generated code (and with it the last bit of
-    // D), so choosing it by batch size would make a trajectory's iterates depend on how many neighbours it has.  Measured at C2
-    // (512 wavefronts per task): G = 1: 91 us, 2: 56 us, 3: 52 us, NQ: 65 us per launch.
-    constexpr int G = 3;
-    hipLaunchKernelGGL((kkt_kernel<M, G>), dim3(cdiv((long)s->B * s->N, 64), G + 1), dim3(64), 0, st, s->bf, s->cw, s->N, s->B, dt);
+    // Two tasks for EVERY batch size: the split changes the generated code (and with it the last bit of D), so choosing it by batch
+    // size would make a trajectory's iterates depend on how many neighbours it has.
+    hipLaunchKernelGGL((kkt_kernel<M>), dim3(cdiv((long)s->B * s->N, 64), 2), dim3(64), 0, st, s->bf, s->cw, s->N, s->B, dt);
 }
 template<class M> static bool pcg_folds_stair(const GatoSolver* s);
 template<class M> static void launch_schur(GatoSolver* s, hipStream_t st, float dt, bool force_stair = false)

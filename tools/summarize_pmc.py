@@ -15,7 +15,7 @@ import sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-STAGE = [("pcg", r"pcgc?_kernel"), ("kkt", r"kkt_kernel"), ("schur", r"schur2?_kernel"), ("merit", r"merit_kernel"), ("dz", r"dz_kernel"),
+STAGE = [("pcg", r"pcgc?_kernel"), ("kkt", r"kkt_kernel"), ("schur", r"schur2?_kernel|pinv_kernel"), ("merit", r"merit_kernel"), ("dz", r"dz_kernel"),
          ("line_search", r"line_search_kernel")]
 
 
