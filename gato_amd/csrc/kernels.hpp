@@ -381,14 +381,23 @@ template<int n, bool THREE> GATO_DEV void gj_inverse(float* Mat)
 // NOT inlined on purpose: with G tasks inlined into one kernel the code object grows past the +-128 KB reach of s_cbranch
 // (325 KB for iiwa14, G = 7) and the compiler's long-branch relaxation produced wrong results on gfx950 / ROCm 7.2 (columns of D
 // corrupted when f_ext != 0; caught by tests/test_gpu_parity.py).  As real functions every task body stays below 64 KB and is
-// reached through s_swappc; x / fe travel through private memory.
-template<class M, int J0, int CNT>
-__device__ __noinline__ void kkt_columns(float* __restrict__ D, float* __restrict__ c_out, const float* x, const float* fe, float dt)
+// reached through s_swappc.  not_tail_called: a call marked `tail` disables the no-callee-saved-registers optimisation and the task
+// would open with ~110 scratch stores of caller registers nobody needs.
+template<class M, int JA, int JB>
+__device__ __noinline__ __attribute__((not_tail_called)) void kkt_columns(float* __restrict__ D, float* __restrict__ c_out, const float* __restrict__ xu,
+                                         const float* __restrict__ f_ext, float dt)
 {
     constexpr int NQ = M::NQ, NX = 2 * NQ, NU = NQ, KS = NX + NU;
+    // the knot's [x_k u_k x_{k+1}] and the wrench are fetched HERE, once, into registers: handed over through private memory they
+    // were re-read (flat_load + s_waitcnt 0) a dozen times along the chain
+    float x[KS + NX], fe[6];
+#pragma unroll
+    for (int i = 0; i < KS + NX; i++) x[i] = xu[i];
+#pragma unroll
+    for (int i = 0; i < 6; i++) fe[i] = f_ext[i];
     RBD<M> d;
     d.set_q(x);
-    d.template fd_grad_columns<J0, CNT>(
+    d.template fd_grad_columns<JA, JB>(
         x + NQ, x + NX, fe,
         [&](int J, const float* cq, const float* cd, const float* cm) {
             store_vec<NQ, NQ>(D + J * NQ, cq);
@@ -396,7 +405,7 @@ __device__ __noinline__ void kkt_columns(float* __restrict__ D, float* __restric
             store_vec<NQ, NQ>(D + 2 * NQ * NQ + J * NQ, cm);
         },
         [&](const float* qdd) {
-            if constexpr (J0 == 0) {
+            if constexpr (JA == 0) {
                 float c[NX];
 #pragma unroll
                 for (int i = 0; i < NQ; i++) {
@@ -440,37 +449,47 @@ GATO_DEV void kkt_costs(const Buffers& bf, const Costs& cw, const float* x, cons
     if (!terminal) store_vec<NU, NU>(bf.Rdi + bk * NU, Rd);
 }
 
-// Two tasks (grid.y = 2), one wavefront of 64 (b,k) lanes each, the same split for every batch size (results do not depend on B):
-//   task 0: forward dynamics, defect c_{k+1}, derivative columns [0, NQ/2)            (the long columns)
-//   task 1: forward dynamics, derivative columns [NQ/2, NQ), then the cost blocks of knot k; its lane k = N-1 -- idle in the
-//           column part -- produces the terminal blocks from x_{N-2} and c_0 = x_0 - x_s.
-// Both tasks are ~7 k instructions; B x N / 64 x 2 wavefronts is one round on the chip's 1024 SIMDs at C2.
-template<class M>
-__global__ __launch_bounds__(64) void kkt_kernel(Buffers bf, Costs cw, int N, int B, float dt)
+// Tasks (grid.y = NT = (NQ+1)/2 + 1), one wavefront of 64 (b,k) lanes each, the same split for every batch size (results do not
+// depend on B):
+//   task g < NT-1: forward dynamics and the derivative columns g and NQ-1-g (a long and a short one: the cost of column J falls
+//                  with J); task 0 also stores the defect c_{k+1}
+//   task NT-1    : the cost blocks of knot k; its lane k = N-1 produces the terminal blocks from x_{N-2} and c_0 = x_0 - x_s.
+// __launch_bounds__(64, 2): two wavefronts per SIMD.  A lone wavefront issues one dependent VALU instruction per ~10 cycles; the
+// second one fills the gaps, which pays for the few spills the 256-register budget costs.
+template<class M, int g> GATO_DEV void kkt_dispatch(int task, const Buffers& bf, const float* xu, const float* fe, size_t bk, float dt)
 {
-    constexpr int NQ = M::NQ, NX = 2 * NQ, NU = NQ, KS = NX + NU, H = NQ / 2;
+    constexpr int NQ = M::NQ, NX = 2 * NQ;
+    if constexpr (g < (NQ + 1) / 2) {
+        if (task == g)
+            kkt_columns<M, g, NQ - 1 - g>(bf.D + bk * 3 * NQ * NQ, bf.c + (bk + 1) * NX, xu, fe, dt);
+        else
+            kkt_dispatch<M, g + 1>(task, bf, xu, fe, bk, dt);
+    }
+}
+
+template<class M>
+__global__ __launch_bounds__(64, 2) void kkt_kernel(Buffers bf, Costs cw, int N, int B, float dt)
+{
+    constexpr int NQ = M::NQ, NX = 2 * NQ, NU = NQ, KS = NX + NU, NT = (NQ + 1) / 2 + 1;
     if (bf.ctrl->done) return;
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     const int k = g % N, b = g / N;
     const int task = blockIdx.y;  // wave-uniform
     if (b >= B) return;
     const bool last = (k == N - 1);
-    if (last && task == 0) return;
+    if (last && task != NT - 1) return;
     const int traj = KS * N - NU;
     const int kx = last ? N - 2 : k;  // the terminal lane reads knot N-2
     const float* xu = bf.xu + (size_t)b * traj + (size_t)kx * KS;
     const size_t bk = (size_t)b * N + k;
-    float x[KS + NX], fe[6];
-#pragma unroll
-    for (int i = 0; i < KS + NX; i++) x[i] = xu[i];
-#pragma unroll
-    for (int i = 0; i < 6; i++) fe[i] = bf.f_ext[6 * b + i];
-    if (task == 0) {
-        kkt_columns<M, 0, H>(bf.D + bk * 3 * NQ * NQ, bf.c + (bk + 1) * NX, x, fe, dt);
+    if (task != NT - 1) {
+        kkt_dispatch<M, 0>(task, bf, xu, bf.f_ext + 6 * b, bk, dt);
         return;
     }
-    if (!last) kkt_columns<M, H, NQ - H>(bf.D + bk * 3 * NQ * NQ, nullptr, x, fe, dt);
-    kkt_costs<M>(bf, cw, x, bf.ref + (size_t)b * 6 * N + 6 * (last ? N - 1 : k), bk, bf.rho[b], last);
+    float x[KS + NX];
+#pragma unroll
+    for (int i = 0; i < KS + NX; i++) x[i] = xu[i];
+    kkt_costs<M>(bf, cw, x, bf.ref + (size_t)b * 6 * N + 6 * k, bk, bf.rho[b], last);
     if (last) {
         float c0[NX];
         const float* x0 = bf.xu + (size_t)b * traj;

@@ -443,35 +443,33 @@ struct RBD {
         }
     }
     // column J of [dqdd/dq | dqdd/dqd | M^-1]: the three nq-vectors D[J], D[nq+J], D[2nq+J] of the compact KKT storage
-    // Columns J0 .. J0+CNT-1 of [dqdd/dq | dqdd/dqd | M^-1] after ONE evaluation of the common prefix (M^-1, RNEA, qdd, RNEA at qdd):
+    // Columns of [dqdd/dq | dqdd/dqd | M^-1] after ONE evaluation of the common prefix (M^-1, RNEA, qdd, RNEA at qdd):
     // `emit(J, colq, cold, colm)` receives each column, `after_qdd(qdd)` runs as soon as the accelerations are known (the defect
     // c_{k+1} is formed there by the task that owns column 0).
-    template<int J, int JEND, class E> GATO_DEV void grad_columns_loop(const float* qd, const float (*v)[6], const float (*a)[6],
-                                                                       const float (*f)[6], const float (*Iv)[6], const MinvT& Mi, E&& emit) const
+    template<int J, class E> GATO_DEV void grad_column(const float* qd, const float (*v)[6], const float (*a)[6], const float (*f)[6],
+                                                       const MinvT& Mi, E&& emit) const
     {
-        if constexpr (J < JEND) {
-            float dcq[NQ], dcd[NQ];
-            rnea_grad_col<J>(qd, v, a, f, Iv, dcq, dcd);
-            if (opaque_true()) {
-                float colq[NQ], cold[NQ], colm[NQ];
+        float dcq[NQ], dcd[NQ];
+        rnea_grad_col<J>(qd, v, a, f, nullptr, dcq, dcd);
+        if (opaque_true()) {
+            float colq[NQ], cold[NQ], colm[NQ];
 #pragma unroll
-                for (int r = 0; r < NQ; r++) {
-                    float s1 = 0.f, s2 = 0.f;
+            for (int r = 0; r < NQ; r++) {
+                float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-                    for (int c = 0; c < NQ; c++) {
-                        s1 += Mi.sym(r, c) * dcq[c];
-                        s2 += Mi.sym(r, c) * dcd[c];
-                    }
-                    colq[r] = -s1;
-                    cold[r] = -s2;
-                    colm[r] = Mi.sym(r, J);
+                for (int c = 0; c < NQ; c++) {
+                    s1 += Mi.sym(r, c) * dcq[c];
+                    s2 += Mi.sym(r, c) * dcd[c];
                 }
-                emit(J, colq, cold, colm);
+                colq[r] = -s1;
+                cold[r] = -s2;
+                colm[r] = Mi.sym(r, J);
             }
-            grad_columns_loop<J + 1, JEND>(qd, v, a, f, Iv, Mi, emit);
+            emit(J, colq, cold, colm);
         }
     }
-    template<int J0, int CNT, class E, class F> GATO_DEV void fd_grad_columns(const float* qd, const float* u, const float* fext, E&& emit,
+    // columns JA and JB (JB == JA: one column) after one evaluation of the common prefix
+    template<int JA, int JB, class E, class F> GATO_DEV void fd_grad_columns(const float* qd, const float* u, const float* fext, E&& emit,
                                                                               F&& after_qdd) const
     {
         // phases in basic blocks of their own (see rnea_grad_col)
@@ -484,7 +482,8 @@ struct RBD {
             after_qdd(qdd);
         }
         if (opaque_true()) rnea(qd, qdd, fext, v, a, f);
-        grad_columns_loop<J0, J0 + CNT>(qd, v, a, f, nullptr, Mi, emit);
+        grad_column<JA>(qd, v, a, f, Mi, emit);
+        if constexpr (JB != JA) grad_column<JB>(qd, v, a, f, Mi, emit);
     }
     template<int K> GATO_DEV void all_Iv(const float (*v)[6], float (*Iv)[6]) const
     {

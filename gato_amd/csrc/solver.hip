@@ -161,9 +161,10 @@ template<class M> static void launch_merit(GatoSolver* s, hipStream_t st, int na
 }
 template<class M> static void launch_kkt(GatoSolver* s, hipStream_t st, float dt)
 {
-    // Two tasks for EVERY batch size: the split changes the generated code (and with it the last bit of D), so choosing it by batch
-    // size would make a trajectory's iterates depend on how many neighbours it has.
-    hipLaunchKernelGGL((kkt_kernel<M>), dim3(cdiv((long)s->B * s->N, 64), 2), dim3(64), 0, st, s->bf, s->cw, s->N, s->B, dt);
+    // The same task split for EVERY batch size: it changes the generated code (and with it the last bit of D), so choosing it by
+    // batch size would make a trajectory's iterates depend on how many neighbours it has.
+    constexpr int NT = (M::NQ + 1) / 2 + 1;
+    hipLaunchKernelGGL((kkt_kernel<M>), dim3(cdiv((long)s->B * s->N, 64), NT), dim3(64), 0, st, s->bf, s->cw, s->N, s->B, dt);
 }
 template<class M> static bool pcg_folds_stair(const GatoSolver* s);
 template<class M> static void launch_schur(GatoSolver* s, hipStream_t st, float dt, bool force_stair = false)
