@@ -502,21 +502,12 @@ __global__ __launch_bounds__(64, 2) void kkt_kernel(Buffers bf, Costs cw, int N,
 // =========================================================================================================================
 // Schur complement formation (schur_linsys.cuh:14-211), one lane per (b,k).
 // =========================================================================================================================
+// the Q_0 row (schur_linsys.cuh:166-210) of trajectory b, by one lane
 template<class M>
-__global__ __launch_bounds__(64) void schur_kernel(Buffers bf, int N, int B, float dt)
+GATO_DEV void schur_row0(const Buffers& bf, int N, int b, float rho, float* S, float* P, float* gam)
 {
-    constexpr int NQ = M::NQ, NX = 2 * NQ, NU = NQ, BR = 3 * NX, BROW = 3 * NX * NX;
-    if (bf.ctrl->done) return;
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    const int k = g % N, b = g / N;
-    if (b >= B) return;
-    const size_t bk = (size_t)b * N + k;
-    const float rho = bf.rho[b];
-    float* S = bf.S + (size_t)b * N * BROW;
-    float* P = bf.Pinv + (size_t)b * N * BROW;
-    float* gam = bf.gamma + (size_t)b * (N + 2) * NX;
-
-    if (k == N - 1) {
+    constexpr int NQ = M::NQ, NX = 2 * NQ, BR = 3 * NX;
+    {
         // the Q_0 row (schur_linsys.cuh:166-210): P^-1 row 0 = -(Q_0 + rho I_q), S row 0 = -(Q_0 + rho I_q)^-1, gamma_0 = c_0 - Q_0^-1 q_0
         const size_t b0 = (size_t)b * N;
         float Qq[NQ * NQ], Qi[NQ * NQ], Qd[NQ], q0[NX], c0[NX];
@@ -569,6 +560,25 @@ __global__ __launch_bounds__(64) void schur_kernel(Buffers bf, int N, int B, flo
             g0[y] = c0[y] + (-s);
         }
         store_vec<NX, NX>(gam + NX, g0);
+    }
+}
+
+template<class M>
+__global__ __launch_bounds__(64) void schur_kernel(Buffers bf, int N, int B, float dt)
+{
+    constexpr int NQ = M::NQ, NX = 2 * NQ, NU = NQ, BR = 3 * NX, BROW = 3 * NX * NX;
+    if (bf.ctrl->done) return;
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    const int k = g % N, b = g / N;
+    if (b >= B) return;
+    const size_t bk = (size_t)b * N + k;
+    const float rho = bf.rho[b];
+    float* S = bf.S + (size_t)b * N * BROW;
+    float* P = bf.Pinv + (size_t)b * N * BROW;
+    float* gam = bf.gamma + (size_t)b * (N + 2) * NX;
+
+    if (k == N - 1) {
+        schur_row0<M>(bf, N, b, rho, S, P, gam);
         return;
     }
 
@@ -667,6 +677,256 @@ __global__ __launch_bounds__(64) void schur_kernel(Buffers bf, int N, int B, flo
             }
             store_vec<2 * NX, NX>(Sk1 + y * BR, row);
             store_vec<NX, NX>(Sk + y * BR + 2 * NX, rt);
+        }
+    }
+}
+
+// ---- cooperative form: LPP lanes per (b,k) ------------------------------------------------------------------------------------
+// Lane l of a group owns the RW = nx / LPP rows y0 = l RW .. of phi_k, theta_k and, after the Gauss-Jordan sweep, of
+// (theta_k + rho I_q)^-1: 4 x the wavefronts of the lane-per-knot form at a quarter of the chain each, ~250 registers, and theta
+// never travels through memory between the two halves (schur_kernel + pinv_kernel wrote and re-read it).  All lanes of a group load
+// the same D_k, Q^-1 (identical addresses: one request per group); their own rows are picked out of the register copy with
+// v_cndmask, never by dynamic indexing.  The pivot row of each elimination step comes from its owner through DPP quad_perm.
+// LPP = 4 needs nq = 2 RW (indy7: rows 3l..3l+2), LPP = 2 needs nq = RW (iiwa14): a lane's rows never straddle the q | qd halves.
+template<int LPP, int O> GATO_DEV float group_bcast(float v)  // lane O of every group of LPP consecutive lanes
+{
+    constexpr int ctrl = (LPP == 4) ? (O * 0x55) : (O | (O << 2) | ((2 + O) << 4) | ((2 + O) << 6));
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, false));
+}
+template<int LPP, int RW, int NX, int P> GATO_DEV void gj_coop_step(float (*W)[NX], int l, float rho_unused)
+{
+    // pivot P: owner lane O = P / RW, its local row I = P % RW
+    constexpr int O = P / RW, I = P % RW;
+    float prow[NX];
+#pragma unroll
+    for (int c = 0; c < NX; c++) prow[c] = group_bcast<LPP, O>(W[I][c]);
+    const float pvInv = 1.0f / prow[P];
+    const bool owner = (l == O);
+#pragma unroll
+    for (int i = 0; i < RW; i++) {
+        const float f = W[i][P] * pvInv;  // colv[r] * pvInv
+#pragma unroll
+        for (int c = 0; c < NX; c++) {
+            float x, yv;
+            if (c == P) {
+                yv = 0.f - f;  // x = 0, rowv = 1
+                x = 1.0f;
+            } else {
+                x = W[i][c];
+                yv = x - f * prow[c];
+            }
+            if (i == I) {
+                const float piv = x * pvInv;  // the pivot row itself (only in the owner lane)
+                yv = owner ? piv : yv;
+            }
+            W[i][c] = yv;
+        }
+    }
+    if constexpr (P + 1 < NX) gj_coop_step<LPP, RW, NX, P + 1>(W, l, rho_unused);
+}
+
+template<class M, int LPP>
+__global__ __launch_bounds__(256) void schurq_kernel(Buffers bf, int N, int B, float dt)
+{
+    constexpr int NQ = M::NQ, NX = 2 * NQ, NU = NQ, RW = NX / LPP, BR = 3 * NX, BROW = 3 * NX * NX;
+    static_assert(NX % LPP == 0 && (RW == NQ || 2 * RW == NQ), "a lane's rows must stay inside one half of the state");
+    if (bf.ctrl->done) return;
+    if (blockIdx.y == 1) {  // the Q_0 rows: one lane per trajectory
+        const int b = blockIdx.x * blockDim.x + threadIdx.x;
+        if (b >= B) return;
+        schur_row0<M>(bf, N, b, bf.rho[b], bf.S + (size_t)b * N * BROW, bf.Pinv + (size_t)b * N * BROW, bf.gamma + (size_t)b * (N + 2) * NX);
+        return;
+    }
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    const int l = threadIdx.x % LPP;
+    const int pidx = g / LPP;
+    const int k = pidx % N, b = pidx / N;
+    if (b >= B || k == N - 1) return;  // whole groups are in or out
+    const size_t bk = (size_t)b * N + k;
+    const float rho = bf.rho[b];
+    const float h2 = half_dt_sq(dt);
+    const int y0 = l * RW;
+    const bool upper = y0 < NQ;                // rows in the q half
+    const bool odd = (RW != NQ) && (l & 1);    // y0 % NQ == RW
+    const float coef = upper ? h2 : dt;
+
+    float phi[RW][NX], th[RW][NX], gg[RW];
+    {
+        float Dm[3 * NQ * NQ], ri[NU];
+        load_vec<3 * NQ * NQ, 3 * NQ * NQ>(Dm, bf.D + bk * 3 * NQ * NQ);
+        load_vec<NU, NU>(ri, bf.Rdi + bk * NU);
+        // own rows of A_k and B_k (row r: r % nq is i or RW + i, picked by lane parity)
+        float Ar[RW][NX], Br[RW][NU];
+#pragma unroll
+        for (int i = 0; i < RW; i++) {
+#pragma unroll
+            for (int c = 0; c < NX; c++) {
+                float d = Dm[c * NQ + i];
+                if constexpr (RW != NQ) d = odd ? Dm[c * NQ + RW + i] : d;
+                // A_elem with a lane-dependent row: delta_rc, + dt at (r, r + nq) in the q half, then + coef * d
+                float v0 = 0.f;
+                if (c < NQ) {
+                    if (c == i) v0 = (upper && !odd) ? 1.0f : 0.f;
+                    if (RW != NQ && c == RW + i) v0 = (upper && odd) ? 1.0f : 0.f;
+                } else {
+                    if (c - NQ == i) v0 = !odd ? (upper ? dt : 1.0f) : 0.f;
+                    if (RW != NQ && c - NQ == RW + i) v0 = odd ? (upper ? dt : 1.0f) : 0.f;
+                }
+                Ar[i][c] = v0 + coef * d;
+            }
+#pragma unroll
+            for (int c = 0; c < NU; c++) {
+                float d = Dm[2 * NQ * NQ + c * NQ + i];
+                if constexpr (RW != NQ) d = odd ? Dm[2 * NQ * NQ + c * NQ + RW + i] : d;
+                Br[i][c] = coef * d;
+            }
+        }
+        if (opaque_true()) {
+            float Qi[NQ * NQ], di[NQ];
+            load_vec<NQ * NQ, NQ * NQ>(Qi, bf.Qqi + bk * NQ * NQ);
+            load_vec<NQ, NQ>(di, bf.Qdi + bk * NQ);
+#pragma unroll
+            for (int i = 0; i < RW; i++)
+#pragma unroll
+                for (int c = 0; c < NQ; c++) {
+                    float sacc = 0.f;
+#pragma unroll
+                    for (int j = 0; j < NQ; j++) sacc += Ar[i][j] * Qi[c * NQ + j];
+                    phi[i][c] = sacc;
+                    phi[i][NQ + c] = Ar[i][NQ + c] * di[c];
+                }
+        }
+        // own rows of Q_{k+1}^-1: tq (q half, zero in qd-half lanes) and the single diagonal entry td (qd half)
+        float tq[RW][NQ], td[RW];
+        if (opaque_true()) {
+            float Qi1[NQ * NQ], di1[NQ];
+            load_vec<NQ * NQ, NQ * NQ>(Qi1, bf.Qqi + (bk + 1) * NQ * NQ);
+            load_vec<NQ, NQ>(di1, bf.Qdi + (bk + 1) * NQ);
+#pragma unroll
+            for (int i = 0; i < RW; i++) {
+#pragma unroll
+                for (int x = 0; x < NQ; x++) {
+                    float v = Qi1[x * NQ + i];
+                    if constexpr (RW != NQ) v = odd ? Qi1[x * NQ + RW + i] : v;
+                    tq[i][x] = upper ? v : 0.f;
+                }
+                float dv = di1[i];
+                if constexpr (RW != NQ) dv = odd ? di1[RW + i] : dv;
+                td[i] = upper ? 0.f : dv;
+            }
+        }
+        // theta rows: Q_{k+1}^-1 + phi A^T + (B R^-1) B^T, one column x at a time (A, B rows of x rebuilt from D)
+        if (opaque_true()) {
+            float Bri[RW][NU];
+#pragma unroll
+            for (int i = 0; i < RW; i++)
+#pragma unroll
+                for (int j = 0; j < NU; j++) Bri[i][j] = Br[i][j] * ri[j];
+#pragma unroll
+            for (int x = 0; x < NX; x++) {
+                float Ax[NX], Bx[NU];
+#pragma unroll
+                for (int j = 0; j < NX; j++) Ax[j] = A_elem<NQ>(Dm, x, j, dt, h2);
+#pragma unroll
+                for (int j = 0; j < NU; j++) Bx[j] = B_elem<NQ>(Dm, x, j, dt, h2);
+#pragma unroll
+                for (int i = 0; i < RW; i++) {
+                    float sacc = 0.f, s2 = 0.f;
+#pragma unroll
+                    for (int j = 0; j < NX; j++) sacc += phi[i][j] * Ax[j];
+#pragma unroll
+                    for (int j = 0; j < NU; j++) s2 += Bri[i][j] * Bx[j];
+                    float t = 0.f;
+                    if (x < NQ) {
+                        t = tq[i][x];
+                    } else {
+                        if (x - NQ == i) t = !odd ? td[i] : 0.f;
+                        if (RW != NQ && x - NQ == RW + i) t = odd ? td[i] : 0.f;
+                    }
+                    t += sacc;
+                    t += s2;
+                    th[i][x] = t;
+                }
+            }
+            // gamma_{k+1} rows
+            float qk[NX], qk1[NX], rk[NU], ck1[NX];
+            load_vec<NX, NX>(qk, bf.q + bk * NX);
+            load_vec<NX, NX>(qk1, bf.q + (bk + 1) * NX);
+            load_vec<NU, NU>(rk, bf.r + bk * NU);
+            load_vec<NX, NX>(ck1, bf.c + (bk + 1) * NX);
+#pragma unroll
+            for (int i = 0; i < RW; i++) {
+                // own entries of c_{k+1} and q_{k+1} (row y0 + i: one of LPP candidates)
+                float cy = ck1[i], qy = qk1[i];
+#pragma unroll
+                for (int m = 1; m < LPP; m++) {
+                    cy = (l == m) ? ck1[m * RW + i] : cy;
+                    qy = (l == m) ? qk1[m * RW + i] : qy;
+                }
+                float g1 = -1.0f * cy;
+                float sq = 0.f;
+#pragma unroll
+                for (int j = 0; j < NQ; j++) sq += tq[i][j] * qk1[j];
+                const float sd = td[i] * qy;
+                g1 += upper ? sq : sd;
+                float sacc = 0.f;
+#pragma unroll
+                for (int j = 0; j < NX; j++) sacc += phi[i][j] * qk[j];
+                g1 += -sacc;
+                sacc = 0.f;
+#pragma unroll
+                for (int j = 0; j < NU; j++) sacc += Bri[i][j] * rk[j];
+                g1 += -sacc;
+                gg[i] = -1.0f * g1;
+            }
+        }
+    }
+    float* S = bf.S + (size_t)b * N * BROW;
+    float* Sk = S + (size_t)k * BROW;
+    float* Sk1 = S + (size_t)(k + 1) * BROW;
+    if (opaque_true()) {
+        // S row k+1: [phi | -theta] (own rows, 16-byte stores); S row k right block = phi^T: the lane's RW rows of phi are RW
+        // consecutive entries of every transposed row
+#pragma unroll
+        for (int i = 0; i < RW; i++) {
+            float row[2 * NX];
+#pragma unroll
+            for (int x = 0; x < NX; x++) {
+                row[x] = phi[i][x];
+                row[NX + x] = -th[i][x];
+            }
+            store_vec<2 * NX, NX>(Sk1 + (size_t)(y0 + i) * BR, row);
+        }
+#pragma unroll
+        for (int x = 0; x < NX; x++) {
+            float* dst = Sk + (size_t)x * BR + 2 * NX + y0;
+#pragma unroll
+            for (int i = 0; i < RW; i++) dst[i] = phi[i][x];
+        }
+        float* gam = bf.gamma + (size_t)b * (N + 2) * NX + (size_t)(k + 2) * NX + y0;
+#pragma unroll
+        for (int i = 0; i < RW; i++) gam[i] = gg[i];
+    }
+    // P^-1 row k+1 main = -(theta_k + rho I_q)^-1 (schur_linsys.cuh:150-164), Gauss-Jordan across the group
+    if (opaque_true()) {
+#pragma unroll
+        for (int i = 0; i < RW; i++) {
+            // + rho on the first nq diagonal entries: row y0 + i, column y0 + i
+            if constexpr (RW == NQ) {
+                th[i][i] += upper ? rho : 0.f;
+            } else {
+                th[i][i] += (upper && !odd) ? rho : 0.f;
+                th[i][RW + i] += (upper && odd) ? rho : 0.f;
+            }
+        }
+        gj_coop_step<LPP, RW, NX, 0>(th, l, 0.f);
+        float* Pk1 = bf.Pinv + ((size_t)b * N + k + 1) * BROW;
+#pragma unroll
+        for (int i = 0; i < RW; i++) {
+            float row[NX];
+#pragma unroll
+            for (int x = 0; x < NX; x++) row[x] = -th[i][x];
+            store_vec<NX, NX>(Pk1 + (size_t)(y0 + i) * BR + NX, row);
         }
     }
 }
@@ -966,33 +1226,37 @@ __global__ __launch_bounds__(MAXT) void pcg_kernel(Buffers bf, int N, int B, uin
 // the 3 nx-wide window of the input vector: one LDS read of the window feeds RPT rows (LDS traffic / RPT) and the RPT dot products
 // give the FMA stream its ILP.  With RPT = 6 an indy7 N = 32 trajectory is ONE wavefront (64 lanes x 6 rows): 432 matrix registers
 // per lane, no cross-wave barrier at all, and four trajectories co-resident per CU (one per SIMD).
+// Packed FP32: each row keeps an (even, odd) pair of partial sums and advances it with v_pk_fma_f32 -- two FMAs per issued
+// instruction; the matrix rows already sit in consecutive registers and the window arrives as 16-byte LDS reads, so no packing
+// moves are needed.  The pair is added once at the end.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 template<int NXT, int RPT> GATO_DEV void rows_dot(const float (*rows)[3 * NXT], const float* __restrict__ win, float* acc)
 {
+    f32x2 a2[RPT];
 #pragma unroll
-    for (int u = 0; u < RPT; u++) acc[u] = 0.f;
+    for (int u = 0; u < RPT; u++) a2[u] = f32x2{0.f, 0.f};
     if constexpr (NXT % 4 == 0) {
 #pragma unroll
         for (int c = 0; c < 3 * NXT / 4; c++) {
             const float4 v = reinterpret_cast<const float4*>(win)[c];
+            const f32x2 lo = {v.x, v.y}, hi = {v.z, v.w};
 #pragma unroll
             for (int u = 0; u < RPT; u++) {
-                acc[u] += rows[u][4 * c] * v.x;
-                acc[u] += rows[u][4 * c + 1] * v.y;
-                acc[u] += rows[u][4 * c + 2] * v.z;
-                acc[u] += rows[u][4 * c + 3] * v.w;
+                a2[u] = __builtin_elementwise_fma(f32x2{rows[u][4 * c], rows[u][4 * c + 1]}, lo, a2[u]);
+                a2[u] = __builtin_elementwise_fma(f32x2{rows[u][4 * c + 2], rows[u][4 * c + 3]}, hi, a2[u]);
             }
         }
     } else {
 #pragma unroll
         for (int c = 0; c < 3 * NXT / 2; c++) {
             const float2 v = reinterpret_cast<const float2*>(win)[c];
+            const f32x2 w = {v.x, v.y};
 #pragma unroll
-            for (int u = 0; u < RPT; u++) {
-                acc[u] += rows[u][2 * c] * v.x;
-                acc[u] += rows[u][2 * c + 1] * v.y;
-            }
+            for (int u = 0; u < RPT; u++) a2[u] = __builtin_elementwise_fma(f32x2{rows[u][2 * c], rows[u][2 * c + 1]}, w, a2[u]);
         }
     }
+#pragma unroll
+    for (int u = 0; u < RPT; u++) acc[u] = a2[u].x + a2[u].y;
 }
 
 // FOLD: the stair off-diagonals of P^-1 (formSchurSystemBatchedKernel2, schur_linsys.cuh:213-260) are formed HERE, from the stored
