@@ -233,13 +233,15 @@ template<class M> static void launch_pcg(GatoSolver* s, hipStream_t st, int sqp_
     }
     const int v = g_pcg_variant;
     // register-resident, contiguous rows: the fewest waves per trajectory that fit the register file
-    // measured at indy7 N=32 B=1024 (profiles/r01b_pcg_variants.txt): 2 rows/thread 170 us, 3 rows 184 us, 6 rows (one wave per
-    // trajectory) 254 us, strided one row per thread 280 us per launch
+    // measured at indy7 N=32 B=1024 (profiles/r01d_pcg_variants.txt): 3 rows/thread 151 us, 2 rows 172 us, 1 row 213 us, 6 rows (one
+    // wave per trajectory) 217 us per launch
     if (v == 4 && try_pcgc<M, 2, 3>(s, st, sqp_iter, lds, fold, write_p)) return;
     if (v == 6 && try_pcgc<M, 1>(s, st, sqp_iter, lds, fold, write_p)) return;     // 1 row/thread, 6 waves per indy7 N=32 trajectory
     if (v == 5 && try_pcgc<M, 3, 2>(s, st, sqp_iter, lds, fold, write_p)) return;  // 3 rows/thread in 256 registers
-    if ((v == 100 || v == 3) && try_pcgc<M, 2>(s, st, sqp_iter, lds, fold, write_p)) return;
+    // 3 rows per thread first: 256 registers without spills = two wavefronts per SIMD = four 2-wave trajectories per CU, so all
+    // 1024 trajectories of C2 are resident at once (2 rows per thread: 200+ registers, two trajectories per CU, two rounds)
     if ((v == 100 || v == 2) && try_pcgc<M, 3>(s, st, sqp_iter, lds, fold, write_p)) return;
+    if ((v == 100 || v == 3) && try_pcgc<M, 2>(s, st, sqp_iter, lds, fold, write_p)) return;
     if ((v == 100 || v == 1) && try_pcgc<M, 6>(s, st, sqp_iter, lds, fold, write_p)) return;
     const int T1 = ((rows + 63) / 64) * 64;
     if (T1 <= 512) {
