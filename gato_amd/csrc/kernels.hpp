@@ -170,25 +170,14 @@ GATO_DEV float seg_sum(float v, int seg, float* lds_part)
 // merit: M_b(alpha) = sum_k cost_k + mu_b (sum_k |x_{k+1} - f(x_k,u_k)|_1 + |x_0 - x_s|_1) at xu + alpha dz   (merit.cuh:17-92)
 // one lane per (b, alpha, k); grid-stride free: thread g -> k = g % N, a = (g / N) % NA, b = g / (N NA)
 // =========================================================================================================================
-template<class M, int NA>
-__global__ __launch_bounds__(256) void merit_kernel(Buffers bf, Costs cw, int N, int B, float dt, int use_dz, int sqp_iter, float thresh,
-                                                    float* __restrict__ out)
+// one lane's term of the merit function: knot k of trajectory b at xu + alpha dz (dzb: the trajectory's step, global or LDS)
+template<class M>
+GATO_DEV float merit_term(const Buffers& bf, const Costs& cw, int N, int b, int k, float alpha, int use_dz, const float* dzb, float dt)
 {
     constexpr int NQ = M::NQ, NX = 2 * NQ, NU = NQ, KS = NX + NU;
-    __shared__ float part[4];
-    if (sqp_iter >= 0) {
-        if (bf.ctrl->done) return;
-        if ((float)bf.num_solved[sqp_iter] >= thresh) return;  // loop breaks before the line search (bsqp.cuh:165)
-    }
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    const int k = g % N, ai = (g / N) % NA;
-    int b = g / (N * NA);
-    const bool live = b < B;
-    if (!live) b = B - 1;
     const int traj = KS * N - NU;
-    const float alpha = (float)(1.0 / (double)(1 << ai));
     const float* xu = bf.xu + (size_t)b * traj + (size_t)k * KS;
-    const float* dz = bf.dz + (size_t)b * traj + (size_t)k * KS;
+    const float* dz = dzb + (size_t)k * KS;
     const bool last = (k == N - 1);
 
     // [x_k, u_k, x_{k+1}] + alpha [dz...]; the last knot has x only.  Loads are UNCONDITIONAL (a branch around a load makes hipcc wait for
@@ -265,7 +254,7 @@ __global__ __launch_bounds__(256) void merit_kernel(Buffers bf, Costs cw, int N,
         }
     } else {
         const float* x0 = bf.xu + (size_t)b * traj;
-        const float* dz0 = bf.dz + (size_t)b * traj;
+        const float* dz0 = dzb;
 #pragma unroll
         for (int i = 0; i < NX; i++) {
             float v = x0[i];
@@ -273,7 +262,26 @@ __global__ __launch_bounds__(256) void merit_kernel(Buffers bf, Costs cw, int N,
             con += fabsf(v - bf.x_s[(size_t)b * NX + i]);
         }
     }
-    float m = cost + bf.mu[b] * con;
+    return cost + bf.mu[b] * con;
+}
+
+template<class M, int NA>
+__global__ __launch_bounds__(256) void merit_kernel(Buffers bf, Costs cw, int N, int B, float dt, int use_dz, int sqp_iter, float thresh,
+                                                    float* __restrict__ out)
+{
+    constexpr int NQ = M::NQ, NX = 2 * NQ, NU = NQ, KS = NX + NU;
+    __shared__ float part[4];
+    if (sqp_iter >= 0) {
+        if (bf.ctrl->done) return;
+        if ((float)bf.num_solved[sqp_iter] >= thresh) return;  // loop breaks before the line search (bsqp.cuh:165)
+    }
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    const int k = g % N, ai = (g / N) % NA;
+    int b = g / (N * NA);
+    const bool live = b < B;
+    if (!live) b = B - 1;
+    const float alpha = (float)(1.0 / (double)(1 << ai));
+    float m = merit_term<M>(bf, cw, N, b, k, alpha, use_dz, bf.dz + (size_t)b * (KS * N - NU), dt);
     m = seg_sum(m, N, part);
     if (live && k == 0) out[b * NA + ai] = m;
 }
@@ -468,10 +476,16 @@ template<class M, int g> GATO_DEV void kkt_dispatch(int task, const Buffers& bf,
 }
 
 template<class M>
-__global__ __launch_bounds__(64, 2) void kkt_kernel(Buffers bf, Costs cw, int N, int B, float dt)
+__global__ __launch_bounds__(64, 2) void kkt_kernel(Buffers bf, Costs cw, int N, int B, float dt, int sqp_iter, float thresh)
 {
     constexpr int NQ = M::NQ, NX = 2 * NQ, NU = NQ, KS = NX + NU, NT = (NQ + 1) / 2 + 1;
     if (bf.ctrl->done) return;
+    if (sqp_iter > 0 && (float)bf.num_solved[sqp_iter - 1] >= thresh) {
+        // the previous iteration ended the loop (bsqp.cuh:165): raise `done` for everything that follows; whether a workgroup sees the
+        // flag or the count, it leaves
+        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) bf.ctrl->done = 1;
+        return;
+    }
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     const int k = g % N, b = g / N;
     const int task = blockIdx.y;  // wave-uniform
@@ -1446,15 +1460,11 @@ __global__ __launch_bounds__(MAXT) void pcgc_kernel(Buffers bf, int N, int B, ui
 // =========================================================================================================================
 // dz recovery (computeDzBatchedKernel, schur_linsys.cuh:316-431), one lane per (b,k); q, r are overwritten by the KKT residuals
 // =========================================================================================================================
+// dz of knot k of trajectory b (computeDz, kkt.cuh), also left in `mirror` (the trajectory's step in LDS) when given
 template<class M>
-__global__ __launch_bounds__(256) void dz_kernel(Buffers bf, int N, int B, float dt, int sqp_iter)
+GATO_DEV void dz_knot(const Buffers& bf, int N, int b, int k, float dt, float* mirror)
 {
     constexpr int NQ = M::NQ, NX = 2 * NQ, NU = NQ, KS = NX + NU;
-    if (bf.ctrl->done) return;
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g == 0) bf.ctrl->iters_done = sqp_iter + 1;
-    const int k = g % N, b = g / N;
-    if (b >= B) return;
     const size_t bk = (size_t)b * N + k;
     const int traj = KS * N - NU;
     const float* lam = bf.lambda + (size_t)b * (N + 2) * NX;
@@ -1500,6 +1510,10 @@ __global__ __launch_bounds__(256) void dz_kernel(Buffers bf, int N, int B, float
 #pragma unroll
             for (int i = 0; i < NX; i++) dz[i] = out[i];  // last knot: dz + k*KS is only 8-byte aligned in general
         }
+        if (mirror) {
+#pragma unroll
+            for (int i = 0; i < NX; i++) mirror[(size_t)k * KS + i] = out[i];
+        }
         store_vec<NX, NX>(bf.q + bk * NX, res);
     }
     // control row
@@ -1523,22 +1537,31 @@ __global__ __launch_bounds__(256) void dz_kernel(Buffers bf, int N, int B, float
         }
 #pragma unroll
         for (int i = 0; i < NU; i++) dz[NX + i] = out[i];
+        if (mirror) {
+#pragma unroll
+            for (int i = 0; i < NU; i++) mirror[(size_t)k * KS + NX + i] = out[i];
+        }
         store_vec<NU, NU>(rk, su);
     }
+}
+
+template<class M>
+__global__ __launch_bounds__(256) void dz_kernel(Buffers bf, int N, int B, float dt, int sqp_iter)
+{
+    if (bf.ctrl->done) return;
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g == 0) bf.ctrl->iters_done = sqp_iter + 1;
+    const int k = g % N, b = g / N;
+    if (b >= B) return;
+    dz_knot<M>(bf, N, b, k, dt, nullptr);
 }
 
 // =========================================================================================================================
 // line search + trajectory update + rho adaptation (line_search.cuh:13-98): one workgroup per trajectory
 // =========================================================================================================================
-__global__ __launch_bounds__(128) void line_search_kernel(Buffers bf, int traj, int B, int adapt_rho, int sqp_iter, float thresh)
+// the line search of trajectory b by its workgroup: mer = the 8 merits, dz = the step (global or LDS)
+GATO_DEV void line_search_block(const Buffers& bf, int b, int B, int traj, const float* mer, const float* dz, int adapt_rho, int sqp_iter)
 {
-    if (bf.ctrl->done) return;
-    if ((float)bf.num_solved[sqp_iter] >= thresh) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) bf.ctrl->done = 1;  // every block takes the same branch; later kernels see done
-        return;
-    }
-    const int b = blockIdx.x;
-    float* mer = bf.merit + (size_t)b * NUM_ALPHAS;
     float best = 1e38f;
     uint32_t idx = 0;
 #pragma unroll
@@ -1571,9 +1594,51 @@ __global__ __launch_bounds__(128) void line_search_kernel(Buffers bf, int traj, 
     if (success) {
         const float step = (float)(1.0 / (double)(1 << idx));
         float* x = bf.xu + (size_t)b * traj;
-        const float* dz = bf.dz + (size_t)b * traj;
         for (int i = threadIdx.x; i < traj; i += blockDim.x) x[i] += step * dz[i];
     }
+}
+__global__ __launch_bounds__(128) void line_search_kernel(Buffers bf, int traj, int B, int adapt_rho, int sqp_iter, float thresh)
+{
+    if (bf.ctrl->done) return;
+    if ((float)bf.num_solved[sqp_iter] >= thresh) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) bf.ctrl->done = 1;  // every block takes the same branch; later kernels see done
+        return;
+    }
+    const int b = blockIdx.x;
+    line_search_block(bf, b, B, traj, bf.merit + (size_t)b * NUM_ALPHAS, bf.dz + (size_t)b * traj, adapt_rho, sqp_iter);
+}
+
+// dz + merit at the 8 step sizes + line search in ONE launch, a workgroup of 8 N lanes per trajectory (N <= 64): the step never
+// leaves the CU between the three (LDS), two launches and their cache write-back / invalidate are gone.  Lane t < N forms dz_t, then
+// lane t is (alpha index t / N, knot t % N) of the merit evaluation, then all lanes apply the chosen step.
+template<class M>
+__global__ __launch_bounds__(512) void step_kernel(Buffers bf, Costs cw, int N, int B, float dt, int sqp_iter, float thresh, int adapt_rho)
+{
+    constexpr int NQ = M::NQ, NX = 2 * NQ, NU = NQ, KS = NX + NU;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    if (bf.ctrl->done) return;
+    const int b = blockIdx.x, t = threadIdx.x;
+    const int traj = KS * N - NU;
+    float* dzs = lds;
+    float* mer = lds + ((traj + 3) & ~3);
+    if (b == 0 && t == 0) bf.ctrl->iters_done = sqp_iter + 1;
+    if (t < N) dz_knot<M>(bf, N, b, t, dt, dzs);
+    // The loop breaks before the line search (bsqp.cuh:165); every workgroup takes the same branch.  `done` is raised by the NEXT
+    // launch (kkt_kernel): set here it could stop a workgroup of this very launch before its dz.
+    if ((float)bf.num_solved[sqp_iter] >= thresh) return;
+    __syncthreads();
+    {
+        const int k = t % N, ai = t / N;
+        const float alpha = (float)(1.0 / (double)(1 << ai));
+        float m = merit_term<M>(bf, cw, N, b, k, alpha, 1, dzs, dt);
+        m = seg_sum(m, N, nullptr);  // N <= 64: inside one wavefront
+        if (k == 0) {
+            mer[ai] = m;
+            bf.merit[(size_t)b * NUM_ALPHAS + ai] = m;
+        }
+    }
+    __syncthreads();
+    line_search_block(bf, b, B, traj, mer, dzs, adapt_rho, sqp_iter);
 }
 
 // =========================================================================================================================

@@ -159,12 +159,13 @@ template<class M> static void launch_merit(GatoSolver* s, hipStream_t st, int na
         hipLaunchKernelGGL((merit_kernel<M, NUM_ALPHAS>), dim3(cdiv(n, 256)), dim3(256), 0, st, s->bf, s->cw, s->N, s->B, dt, use_dz, sqp_iter,
                            thresh, out);
 }
-template<class M> static void launch_kkt(GatoSolver* s, hipStream_t st, float dt)
+template<class M> static void launch_kkt(GatoSolver* s, hipStream_t st, float dt, int sqp_iter)
 {
     // The same task split for EVERY batch size: it changes the generated code (and with it the last bit of D), so choosing it by
     // batch size would make a trajectory's iterates depend on how many neighbours it has.
     constexpr int NT = (M::NQ + 1) / 2 + 1;
-    hipLaunchKernelGGL((kkt_kernel<M>), dim3(cdiv((long)s->B * s->N, 64), NT), dim3(64), 0, st, s->bf, s->cw, s->N, s->B, dt);
+    hipLaunchKernelGGL((kkt_kernel<M>), dim3(cdiv((long)s->B * s->N, 64), NT), dim3(64), 0, st, s->bf, s->cw, s->N, s->B, dt, sqp_iter,
+                       s->p.solve_ratio * (float)s->B);
 }
 template<class M> static bool pcg_folds_stair(const GatoSolver* s);
 template<class M> static void launch_schur(GatoSolver* s, hipStream_t st, float dt, bool force_stair = false)
@@ -264,6 +265,19 @@ template<class M> static void launch_dz(GatoSolver* s, hipStream_t st, float dt,
 {
     hipLaunchKernelGGL((dz_kernel<M>), dim3(cdiv((long)s->B * s->N, 256)), dim3(256), 0, st, s->bf, s->N, s->B, dt, sqp_iter);
 }
+// dz + merit(8 alphas) + line search in one launch: a workgroup of 8 N lanes per trajectory
+static bool step_fused(const GatoSolver* s)
+{
+    static const int on = getenv("GATO_STEP_FUSED") ? atoi(getenv("GATO_STEP_FUSED")) : 1;
+    return on && NUM_ALPHAS * s->N <= 512 && s->N <= 64;
+}
+template<class M> static void launch_step(GatoSolver* s, hipStream_t st, float dt, int sqp_iter)
+{
+    const float thresh = (float)s->B * s->p.solve_ratio;
+    const size_t lds = (size_t)(((s->traj + 3) & ~3) + 16) * sizeof(float);
+    hipLaunchKernelGGL((step_kernel<M>), dim3(s->B), dim3(NUM_ALPHAS * s->N), lds, st, s->bf, s->cw, s->N, s->B, dt, sqp_iter, thresh,
+                       s->adapt_rho);
+}
 static void launch_ls(GatoSolver* s, hipStream_t st, int sqp_iter)
 {
     const float thresh = (float)s->B * s->p.solve_ratio;
@@ -303,18 +317,23 @@ template<class M> static int solve_impl(GatoSolver* s, float* d_xu, float dt, co
     mark(s, st, ST_MERIT, ei);
     const uint32_t iters = s->p.max_sqp_iters <= s->max_iters_alloc ? s->p.max_sqp_iters : s->max_iters_alloc;
     for (uint32_t it = 0; it < iters; it++) {
-        launch_kkt<M>(s, st, dt);
+        launch_kkt<M>(s, st, dt, (int)it);
         mark(s, st, ST_KKT, ei);
         launch_schur<M>(s, st, dt);
         mark(s, st, ST_SCHUR, ei);
         launch_pcg<M>(s, st, (int)it);
         mark(s, st, ST_PCG, ei);
-        launch_dz<M>(s, st, dt, (int)it);
-        mark(s, st, ST_DZ, ei);
-        launch_merit<M>(s, st, NUM_ALPHAS, dt, 1, (int)it, bf.merit);
-        mark(s, st, ST_MERIT, ei);
-        launch_ls(s, st, (int)it);
-        mark(s, st, ST_LS, ei);
+        if (step_fused(s)) {
+            launch_step<M>(s, st, dt, (int)it);
+            mark(s, st, ST_MERIT, ei);
+        } else {
+            launch_dz<M>(s, st, dt, (int)it);
+            mark(s, st, ST_DZ, ei);
+            launch_merit<M>(s, st, NUM_ALPHAS, dt, 1, (int)it, bf.merit);
+            mark(s, st, ST_MERIT, ei);
+            launch_ls(s, st, (int)it);
+            mark(s, st, ST_LS, ei);
+        }
     }
     launch_merit<M>(s, st, 1, dt, 0, -1, bf.merit_cur);  // final merit of the returned xu (bsqp.cuh:180-182)
     mark(s, st, ST_MERIT, ei);
@@ -624,7 +643,7 @@ template<class M> static int stage_impl(GatoSolver* s, int stage, float dt, floa
     HIPCHK(hipMemsetAsync(bf.num_solved, 0, s->max_iters_alloc * sizeof(uint32_t), st));
     switch (stage) {
         case 0: launch_merit<M>(s, st, NUM_ALPHAS, dt, 1, 0, bf.merit); break;
-        case 1: launch_kkt<M>(s, st, dt); break;
+        case 1: launch_kkt<M>(s, st, dt, 0); break;
         case 2: launch_schur<M>(s, st, dt, true); break;   // stage tests read the complete P^-1
         case 3: launch_pcg<M>(s, st, 0, 1); break;
         case 4: launch_dz<M>(s, st, dt, 0); break;
