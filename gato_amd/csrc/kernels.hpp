@@ -431,13 +431,27 @@ __device__ __noinline__ __attribute__((not_tail_called)) void kkt_columns(float*
 // schur_linsys.cuh:96.  `terminal`: the lane produces the blocks of knot N-1 from x_{N-2} against ref_{N-1} and
 // has no R block.  One uniform instruction stream for both kinds of lane; only the R stores are predicated.
 template<class M>
-GATO_DEV void kkt_costs(const Buffers& bf, const Costs& cw, const float* x, const float* ref, size_t bk, float rho, bool terminal)
+GATO_DEV void schur_row0_regs(float* Qq, const float* Qd, const float* q0, const float* c0, float rho, float* S, float* P, float* gam);
+
+// row0 (only ever true in the k = 0 lane): also form the Q_0 rows of S, P^-1 and gamma_0 here, from the blocks in registers -- the
+// fused Schur + PCG kernel has no lane to spare for them
+template<class M>
+GATO_DEV void kkt_costs(const Buffers& bf, const Costs& cw, const float* x, const float* ref, size_t bk, float rho, bool terminal, bool row0,
+                        const float* x_s, float* S0, float* P0, float* gam0)
 {
     constexpr int NQ = M::NQ, NX = 2 * NQ, NU = NQ;
     RBD<M> d;
     d.set_q(x);
     float Qq[NQ * NQ], Qd[NQ], qv[NX], Rd[NU], rv[NU];
     cost_blocks<M>(d, cw, x, x + NX, ref, Qq, Qd, qv, Rd, rv);
+    if (row0) {
+        float Q0[NQ * NQ], c0[NX];
+#pragma unroll
+        for (int i = 0; i < NQ * NQ; i++) Q0[i] = Qq[i];
+#pragma unroll
+        for (int i = 0; i < NX; i++) c0[i] = x[i] - x_s[i];
+        schur_row0_regs<M>(Q0, Qd, qv, c0, rho, S0, P0, gam0);
+    }
     store_vec<NQ * NQ, NQ * NQ>(bf.Qq + bk * NQ * NQ, Qq);
     store_vec<NQ, NQ>(bf.Qd + bk * NQ, Qd);
     store_vec<NX, NX>(bf.q + bk * NX, qv);
@@ -476,7 +490,7 @@ template<class M, int g> GATO_DEV void kkt_dispatch(int task, const Buffers& bf,
 }
 
 template<class M>
-__global__ __launch_bounds__(64, 2) void kkt_kernel(Buffers bf, Costs cw, int N, int B, float dt, int sqp_iter, float thresh)
+__global__ __launch_bounds__(64, 2) void kkt_kernel(Buffers bf, Costs cw, int N, int B, float dt, int sqp_iter, float thresh, int row0)
 {
     constexpr int NQ = M::NQ, NX = 2 * NQ, NU = NQ, KS = NX + NU, NT = (NQ + 1) / 2 + 1;
     if (bf.ctrl->done) return;
@@ -503,7 +517,9 @@ __global__ __launch_bounds__(64, 2) void kkt_kernel(Buffers bf, Costs cw, int N,
     float x[KS + NX];
 #pragma unroll
     for (int i = 0; i < KS + NX; i++) x[i] = xu[i];
-    kkt_costs<M>(bf, cw, x, bf.ref + (size_t)b * 6 * N + 6 * k, bk, bf.rho[b], last);
+    constexpr int BROW = 3 * NX * NX;
+    kkt_costs<M>(bf, cw, x, bf.ref + (size_t)b * 6 * N + 6 * k, bk, bf.rho[b], last, row0 && k == 0, bf.x_s + (size_t)b * NX,
+                 bf.S + (size_t)b * N * BROW, bf.Pinv + (size_t)b * N * BROW, bf.gamma + (size_t)b * (N + 2) * NX);
     if (last) {
         float c0[NX];
         const float* x0 = bf.xu + (size_t)b * traj;
@@ -518,17 +534,12 @@ __global__ __launch_bounds__(64, 2) void kkt_kernel(Buffers bf, Costs cw, int N,
 // =========================================================================================================================
 // the Q_0 row (schur_linsys.cuh:166-210) of trajectory b, by one lane
 template<class M>
-GATO_DEV void schur_row0(const Buffers& bf, int N, int b, float rho, float* S, float* P, float* gam)
+GATO_DEV void schur_row0_regs(float* Qq, const float* Qd, const float* q0, const float* c0, float rho, float* S, float* P, float* gam)
 {
     constexpr int NQ = M::NQ, NX = 2 * NQ, BR = 3 * NX;
     {
         // the Q_0 row (schur_linsys.cuh:166-210): P^-1 row 0 = -(Q_0 + rho I_q), S row 0 = -(Q_0 + rho I_q)^-1, gamma_0 = c_0 - Q_0^-1 q_0
-        const size_t b0 = (size_t)b * N;
-        float Qq[NQ * NQ], Qi[NQ * NQ], Qd[NQ], q0[NX], c0[NX];
-        load_vec<NQ * NQ, NQ * NQ>(Qq, bf.Qq + b0 * NQ * NQ);
-        load_vec<NQ, NQ>(Qd, bf.Qd + b0 * NQ);
-        load_vec<NX, NX>(q0, bf.q + b0 * NX);
-        load_vec<NX, NX>(c0, bf.c + b0 * NX);
+        float Qi[NQ * NQ];
 #pragma unroll
         for (int i = 0; i < NQ; i++) Qq[i * NQ + i] += rho;
 #pragma unroll
@@ -575,6 +586,19 @@ GATO_DEV void schur_row0(const Buffers& bf, int N, int b, float rho, float* S, f
         }
         store_vec<NX, NX>(gam + NX, g0);
     }
+}
+
+template<class M>
+GATO_DEV void schur_row0(const Buffers& bf, int N, int b, float rho, float* S, float* P, float* gam)
+{
+    constexpr int NQ = M::NQ, NX = 2 * NQ;
+    const size_t b0 = (size_t)b * N;
+    float Qq[NQ * NQ], Qd[NQ], q0[NX], c0[NX];
+    load_vec<NQ * NQ, NQ * NQ>(Qq, bf.Qq + b0 * NQ * NQ);
+    load_vec<NQ, NQ>(Qd, bf.Qd + b0 * NQ);
+    load_vec<NX, NX>(q0, bf.q + b0 * NX);
+    load_vec<NX, NX>(c0, bf.c + b0 * NX);
+    schur_row0_regs<M>(Qq, Qd, q0, c0, rho, S, P, gam);
 }
 
 template<class M>
@@ -739,32 +763,19 @@ template<int LPP, int RW, int NX, int P> GATO_DEV void gj_coop_step(float (*W)[N
     if constexpr (P + 1 < NX) gj_coop_step<LPP, RW, NX, P + 1>(W, l, rho_unused);
 }
 
+// Rows y0 = l RW .. of phi_k, theta_k and gamma_{k+1} in registers (lane l of the group that works on knot k <= N-2)
 template<class M, int LPP>
-__global__ __launch_bounds__(256) void schurq_kernel(Buffers bf, int N, int B, float dt)
+GATO_DEV void schur_coop_rows(const Buffers& bf, int N, int b, int k, int l, float dt, float (*phi)[2 * M::NQ], float (*th)[2 * M::NQ], float* gg)
 {
-    constexpr int NQ = M::NQ, NX = 2 * NQ, NU = NQ, RW = NX / LPP, BR = 3 * NX, BROW = 3 * NX * NX;
+    constexpr int NQ = M::NQ, NX = 2 * NQ, NU = NQ, RW = NX / LPP;
     static_assert(NX % LPP == 0 && (RW == NQ || 2 * RW == NQ), "a lane's rows must stay inside one half of the state");
-    if (bf.ctrl->done) return;
-    if (blockIdx.y == 1) {  // the Q_0 rows: one lane per trajectory
-        const int b = blockIdx.x * blockDim.x + threadIdx.x;
-        if (b >= B) return;
-        schur_row0<M>(bf, N, b, bf.rho[b], bf.S + (size_t)b * N * BROW, bf.Pinv + (size_t)b * N * BROW, bf.gamma + (size_t)b * (N + 2) * NX);
-        return;
-    }
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    const int l = threadIdx.x % LPP;
-    const int pidx = g / LPP;
-    const int k = pidx % N, b = pidx / N;
-    if (b >= B || k == N - 1) return;  // whole groups are in or out
     const size_t bk = (size_t)b * N + k;
-    const float rho = bf.rho[b];
     const float h2 = half_dt_sq(dt);
     const int y0 = l * RW;
     const bool upper = y0 < NQ;                // rows in the q half
     const bool odd = (RW != NQ) && (l & 1);    // y0 % NQ == RW
     const float coef = upper ? h2 : dt;
 
-    float phi[RW][NX], th[RW][NX], gg[RW];
     {
         float Dm[3 * NQ * NQ], ri[NU];
         load_vec<3 * NQ * NQ, 3 * NQ * NQ>(Dm, bf.D + bk * 3 * NQ * NQ);
@@ -895,6 +906,46 @@ __global__ __launch_bounds__(256) void schurq_kernel(Buffers bf, int N, int B, f
             }
         }
     }
+}
+// th <- (theta_k + rho I_q)^-1 across the group (P^-1 row k+1 main = -th, schur_linsys.cuh:150-164)
+template<class M, int LPP>
+GATO_DEV void schur_coop_pinv(float (*th)[2 * M::NQ], int l, float rho)
+{
+    constexpr int NQ = M::NQ, NX = 2 * NQ, RW = NX / LPP;
+    const bool upper = l * RW < NQ;
+    const bool odd = (RW != NQ) && (l & 1);
+#pragma unroll
+    for (int i = 0; i < RW; i++) {
+        // + rho on the first nq diagonal entries: row y0 + i, column y0 + i
+        if constexpr (RW == NQ) {
+            th[i][i] += upper ? rho : 0.f;
+        } else {
+            th[i][i] += (upper && !odd) ? rho : 0.f;
+            th[i][RW + i] += (upper && odd) ? rho : 0.f;
+        }
+    }
+    gj_coop_step<LPP, RW, NX, 0>(th, l, 0.f);
+}
+
+template<class M, int LPP>
+__global__ __launch_bounds__(256) void schurq_kernel(Buffers bf, int N, int B, float dt)
+{
+    constexpr int NQ = M::NQ, NX = 2 * NQ, NU = NQ, RW = NX / LPP, BR = 3 * NX, BROW = 3 * NX * NX;
+    if (bf.ctrl->done) return;
+    if (blockIdx.y == 1) {  // the Q_0 rows: one lane per trajectory
+        const int b = blockIdx.x * blockDim.x + threadIdx.x;
+        if (b >= B) return;
+        schur_row0<M>(bf, N, b, bf.rho[b], bf.S + (size_t)b * N * BROW, bf.Pinv + (size_t)b * N * BROW, bf.gamma + (size_t)b * (N + 2) * NX);
+        return;
+    }
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    const int l = threadIdx.x % LPP;
+    const int pidx = g / LPP;
+    const int k = pidx % N, b = pidx / N;
+    if (b >= B || k == N - 1) return;  // whole groups are in or out
+    const int y0 = l * RW;
+    float phi[RW][NX], th[RW][NX], gg[RW];
+    schur_coop_rows<M, LPP>(bf, N, b, k, l, dt, phi, th, gg);
     float* S = bf.S + (size_t)b * N * BROW;
     float* Sk = S + (size_t)k * BROW;
     float* Sk1 = S + (size_t)(k + 1) * BROW;
@@ -921,19 +972,8 @@ __global__ __launch_bounds__(256) void schurq_kernel(Buffers bf, int N, int B, f
 #pragma unroll
         for (int i = 0; i < RW; i++) gam[i] = gg[i];
     }
-    // P^-1 row k+1 main = -(theta_k + rho I_q)^-1 (schur_linsys.cuh:150-164), Gauss-Jordan across the group
     if (opaque_true()) {
-#pragma unroll
-        for (int i = 0; i < RW; i++) {
-            // + rho on the first nq diagonal entries: row y0 + i, column y0 + i
-            if constexpr (RW == NQ) {
-                th[i][i] += upper ? rho : 0.f;
-            } else {
-                th[i][i] += (upper && !odd) ? rho : 0.f;
-                th[i][RW + i] += (upper && odd) ? rho : 0.f;
-            }
-        }
-        gj_coop_step<LPP, RW, NX, 0>(th, l, 0.f);
+        schur_coop_pinv<M, LPP>(th, l, bf.rho[b]);
         float* Pk1 = bf.Pinv + ((size_t)b * N + k + 1) * BROW;
 #pragma unroll
         for (int i = 0; i < RW; i++) {
@@ -1244,8 +1284,26 @@ __global__ __launch_bounds__(MAXT) void pcg_kernel(Buffers bf, int N, int B, uin
 // instruction; the matrix rows already sit in consecutive registers and the window arrives as 16-byte LDS reads, so no packing
 // moves are needed.  The pair is added once at the end.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-template<int NXT, int RPT> GATO_DEV void rows_dot(const float (*rows)[3 * NXT], const float* __restrict__ win, float* acc)
+template<int NXT, int RPT, bool PACKED = true> GATO_DEV void rows_dot(const float (*rows)[3 * NXT], const float* __restrict__ win, float* acc)
 {
+    if constexpr (!PACKED) {
+        // scalar form: two partial sums per row in the same (even, odd) order as the packed form, so both give the same bits
+        float e[RPT], o[RPT];
+#pragma unroll
+        for (int u = 0; u < RPT; u++) e[u] = o[u] = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3 * NXT / 2; c++) {
+            const float2 v = reinterpret_cast<const float2*>(win)[c];
+#pragma unroll
+            for (int u = 0; u < RPT; u++) {
+                e[u] = __builtin_fmaf(rows[u][2 * c], v.x, e[u]);
+                o[u] = __builtin_fmaf(rows[u][2 * c + 1], v.y, o[u]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < RPT; u++) acc[u] = e[u] + o[u];
+        return;
+    }
     f32x2 a2[RPT];
 #pragma unroll
     for (int u = 0; u < RPT; u++) a2[u] = f32x2{0.f, 0.f};
@@ -1273,12 +1331,51 @@ template<int NXT, int RPT> GATO_DEV void rows_dot(const float (*rows)[3 * NXT], 
     for (int u = 0; u < RPT; u++) acc[u] = a2[u].x + a2[u].y;
 }
 
+// Same dot products with the rows' RIGHT block (the last nx entries) parked in LDS as float4 [chunk][thread] (conflict-free): the
+// iteration loop then needs nx x RPT fewer registers.  Only for nx % 4 == 0.
+template<int NXT, int RPT> GATO_DEV void rows_dot_parked(const float (*rows)[3 * NXT], const float* __restrict__ win, const float4* park, int T,
+                                                         float* acc)
+{
+    static_assert(NXT % 4 == 0, "16-byte chunks");
+    constexpr int CH = NXT / 4;  // chunks per block
+    f32x2 a2[RPT];
+#pragma unroll
+    for (int u = 0; u < RPT; u++) a2[u] = f32x2{0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 2 * CH; c++) {
+        const float4 v = reinterpret_cast<const float4*>(win)[c];
+        const f32x2 lo = {v.x, v.y}, hi = {v.z, v.w};
+#pragma unroll
+        for (int u = 0; u < RPT; u++) {
+            a2[u] = __builtin_elementwise_fma(f32x2{rows[u][4 * c], rows[u][4 * c + 1]}, lo, a2[u]);
+            a2[u] = __builtin_elementwise_fma(f32x2{rows[u][4 * c + 2], rows[u][4 * c + 3]}, hi, a2[u]);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < CH; c++) {
+        const float4 v = reinterpret_cast<const float4*>(win)[2 * CH + c];
+        const f32x2 lo = {v.x, v.y}, hi = {v.z, v.w};
+#pragma unroll
+        for (int u = 0; u < RPT; u++) {
+            const float4 m = park[(u * CH + c) * T];
+            a2[u] = __builtin_elementwise_fma(f32x2{m.x, m.y}, lo, a2[u]);
+            a2[u] = __builtin_elementwise_fma(f32x2{m.z, m.w}, hi, a2[u]);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < RPT; u++) acc[u] = a2[u].x + a2[u].y;
+}
+
 // FOLD: the stair off-diagonals of P^-1 (formSchurSystemBatchedKernel2, schur_linsys.cuh:213-260) are formed HERE, from the stored
 // diagonal blocks, instead of by a kernel of their own: the workgroup holds every block row of the trajectory, so
 // left_k = -Pm_k (phi_{k-1} Pm_{k-1}) and right_k = left_{k+1}^T go through two LDS buffers of N nx^2 floats and straight into the
 // threads' P^-1 rows -- they never touch HBM (write_p != 0 stores them for the stage tests).
-template<class M, int RPT, int MAXT, bool FOLD>
-__global__ __launch_bounds__(MAXT) void pcgc_kernel(Buffers bf, int N, int B, uint32_t max_iters, int sqp_iter, int write_p)
+// FUSE (with FOLD, RPT = nx / 4): the block rows of S, the diagonal of P^-1 and gamma are FORMED here by the cooperative Schur code
+// (schur_coop_rows / schur_coop_pinv: thread t of the PCG layout is lane t % 4 of the group of knot t / 4 - 1) instead of being
+// read back: S and P^-1 never exist in global memory, one launch and ~150 MB of traffic per iteration less.  Block row 0 (the
+// Q_0 rows) comes from the assembly kernel's cost task.
+template<class M, int RPT, int MAXT, bool FOLD, bool FUSE = false>
+__global__ __launch_bounds__(MAXT) void pcgc_kernel(Buffers bf, int N, int B, uint32_t max_iters, int sqp_iter, int write_p, float dt)
 {
     constexpr int NQ = M::NQ, NX = 2 * NQ, BR = 3 * NX, BROW = 3 * NX * NX;
     static_assert(NX % RPT == 0, "rows of one thread must share a block row");
@@ -1304,7 +1401,68 @@ __global__ __launch_bounds__(MAXT) void pcgc_kernel(Buffers bf, int N, int B, ui
         const float* gam = bf.gamma + (size_t)b * vecp;
         float* lam = bf.lambda + (size_t)b * vecp;
         float Srow[RPT][BR], Prow[RPT][BR], xv[RPT], rv[RPT], pv[RPT], zv[RPT], gv[RPT];
-        {
+        if constexpr (FUSE) {
+            static_assert(FOLD && RPT * 4 == NX, "the PCG row layout must coincide with the 4-lane Schur groups");
+            const int l = threadIdx.x & 3;
+            {
+                // every thread runs the group code (block row 0's and idle threads on knot 0: a valid, discarded computation) -- no
+                // branch, so no merged live ranges for the register allocator to spill across the iteration loop
+                float phi[RPT][NX], th[RPT][NX], gg[RPT];
+                schur_coop_rows<M, 4>(bf, N, b, (have && kb >= 1) ? kb - 1 : 0, l, dt, phi, th, gg);
+#pragma unroll
+                for (int u = 0; u < RPT; u++) {
+#pragma unroll
+                    for (int x = 0; x < NX; x++) {
+                        Srow[u][x] = phi[u][x];
+                        Srow[u][NX + x] = -th[u][x];
+                    }
+                    gv[u] = gg[u];
+                }
+                if (opaque_true()) {
+                    schur_coop_pinv<M, 4>(th, l, bf.rho[b]);
+#pragma unroll
+                    for (int u = 0; u < RPT; u++)
+#pragma unroll
+                        for (int x = 0; x < NX; x++) Prow[u][NX + x] = -th[u][x];
+                }
+            }
+            if (opaque_true()) {
+                // block row 0 (the Q_0 rows, written by the assembly kernel's cost task): rows 3l.. are read by every thread (one
+                // cached request per row) and kept by the first group only
+                const float* S = bf.S + (size_t)b * N * BROW + (size_t)(RPT * l) * BR;
+                const float* P = bf.Pinv + (size_t)b * N * BROW + (size_t)(RPT * l) * BR;
+                const bool first = have && kb == 0;
+                float g0[RPT];
+                load_vec<RPT, RPT>(g0, gam + NX + RPT * l);
+#pragma unroll
+                for (int u = 0; u < RPT; u++) {
+                    float sm[NX], pm[NX];
+                    load_vec<NX, NX>(sm, S + u * BR + NX);
+                    load_vec<NX, NX>(pm, P + u * BR + NX);
+#pragma unroll
+                    for (int x = 0; x < NX; x++) {
+                        Srow[u][x] = first ? 0.f : Srow[u][x];
+                        Srow[u][NX + x] = first ? sm[x] : Srow[u][NX + x];
+                        Prow[u][NX + x] = first ? pm[x] : Prow[u][NX + x];
+                    }
+                    gv[u] = first ? g0[u] : gv[u];
+                }
+            }
+            load_vec<RPT, RPT>(xv, lam + NX + rr);
+            // right blocks = the next block row's left block transposed, through LDS
+            float* bufA = partB + 16;
+            const int i0 = rr - kb * NX;
+            if (have) {
+#pragma unroll
+                for (int u = 0; u < RPT; u++) store_vec<NX, 2>(bufA + (kb * NX + i0 + u) * NX, &Srow[u][0]);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < RPT; u++)
+#pragma unroll
+                for (int x = 0; x < NX; x++) Srow[u][2 * NX + x] = (have && kb + 1 < N) ? bufA[((kb + 1) * NX + x) * NX + i0 + u] : 0.f;
+            __syncthreads();  // bufA is reused by the stair fold below
+        } else {
             const float* S = bf.S + (size_t)b * N * BROW + (size_t)rr * BR;
             const float* P = bf.Pinv + (size_t)b * N * BROW + (size_t)rr * BR;
 #pragma unroll
@@ -1384,6 +1542,20 @@ __global__ __launch_bounds__(MAXT) void pcgc_kernel(Buffers bf, int N, int B, ui
                 }
             }
         }
+        // PARK: the right blocks of the P^-1 rows move to the LDS the fold no longer needs
+        constexpr bool PARK = FUSE && FOLD && (NX % 4 == 0);
+        const float4* park = nullptr;
+        if constexpr (PARK) {
+            float4* pk = reinterpret_cast<float4*>(partB + 16) + threadIdx.x;
+            __syncthreads();  // the fold's last readers of bufA are done
+#pragma unroll
+            for (int u = 0; u < RPT; u++)
+#pragma unroll
+                for (int c = 0; c < NX / 4; c++)
+                    pk[(u * (NX / 4) + c) * blockDim.x] = make_float4(Prow[u][2 * NX + 4 * c], Prow[u][2 * NX + 4 * c + 1], Prow[u][2 * NX + 4 * c + 2],
+                                                                      Prow[u][2 * NX + 4 * c + 3]);
+            park = pk;
+        }
         const float* wa = va + kb * NX;
         const float* wb = vb + kb * NX;
         float* oa = va + NX + rr;
@@ -1400,7 +1572,8 @@ __global__ __launch_bounds__(MAXT) void pcgc_kernel(Buffers bf, int N, int B, ui
         for (int u = 0; u < RPT; u++) rv[u] = have ? gv[u] - acc[u] : 0.f;
         if (have) store_vec<RPT, RPT>(ob, rv);
         __syncthreads();
-        rows_dot<NX, RPT>(Prow, wb, acc);  // z = p = P^-1 r
+        if constexpr (PARK) rows_dot_parked<NX, RPT>(Prow, wb, park, blockDim.x, acc);
+        else rows_dot<NX, RPT>(Prow, wb, acc);  // z = p = P^-1 r
         float loc = 0.f;
 #pragma unroll
         for (int u = 0; u < RPT; u++) {
@@ -1431,7 +1604,8 @@ __global__ __launch_bounds__(MAXT) void pcgc_kernel(Buffers bf, int N, int B, ui
                 }
                 if (have) store_vec<RPT, RPT>(ob, rv);
                 __syncthreads();
-                rows_dot<NX, RPT>(Prow, wb, acc);  // z = P^-1 r
+                if constexpr (PARK) rows_dot_parked<NX, RPT>(Prow, wb, park, blockDim.x, acc);
+                else rows_dot<NX, RPT>(Prow, wb, acc);  // z = P^-1 r
                 loc = 0.f;
 #pragma unroll
                 for (int u = 0; u < RPT; u++) {

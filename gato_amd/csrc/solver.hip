@@ -37,6 +37,7 @@ struct GatoSolver {
     GatoParams p;
     Costs cw;
     int adapt_rho;
+    int fuse_schur;  // Schur complement formed inside the PCG kernel (GATO_SCHUR_FUSED, default 1)
     uint32_t max_iters_alloc;
     Buffers bf;
     float *d_xu_own, *d_xs_own, *d_ref_own, *d_merit_init0, *d_drho_init, *d_rho_init, *d_scratch_B;
@@ -96,6 +97,7 @@ extern "C" int gato_create(int plant, int N, int B, const GatoParams* params, Ga
     s->p = *params;
     s->cw = Costs{params->q_cost, params->qd_cost, params->u_cost, params->N_cost, params->q_lim_cost, params->vel_lim_cost, params->ctrl_lim_cost};
     s->adapt_rho = 1;
+    s->fuse_schur = getenv("GATO_SCHUR_FUSED") ? atoi(getenv("GATO_SCHUR_FUSED")) : 1;
     s->profiling = 0;
     s->last_stream = nullptr;
     memset(s->stage_us, 0, sizeof(s->stage_us));
@@ -159,13 +161,13 @@ template<class M> static void launch_merit(GatoSolver* s, hipStream_t st, int na
         hipLaunchKernelGGL((merit_kernel<M, NUM_ALPHAS>), dim3(cdiv(n, 256)), dim3(256), 0, st, s->bf, s->cw, s->N, s->B, dt, use_dz, sqp_iter,
                            thresh, out);
 }
-template<class M> static void launch_kkt(GatoSolver* s, hipStream_t st, float dt, int sqp_iter)
+template<class M> static void launch_kkt(GatoSolver* s, hipStream_t st, float dt, int sqp_iter, int row0 = 0)
 {
     // The same task split for EVERY batch size: it changes the generated code (and with it the last bit of D), so choosing it by
     // batch size would make a trajectory's iterates depend on how many neighbours it has.
     constexpr int NT = (M::NQ + 1) / 2 + 1;
     hipLaunchKernelGGL((kkt_kernel<M>), dim3(cdiv((long)s->B * s->N, 64), NT), dim3(64), 0, st, s->bf, s->cw, s->N, s->B, dt, sqp_iter,
-                       s->p.solve_ratio * (float)s->B);
+                       s->p.solve_ratio * (float)s->B, row0);
 }
 template<class M> static bool pcg_folds_stair(const GatoSolver* s);
 template<class M> static void launch_schur(GatoSolver* s, hipStream_t st, float dt, bool force_stair = false)
@@ -202,10 +204,37 @@ template<class M, int RPT, int FORCE_WPS = 0> static bool try_pcgc(GatoSolver* s
         if (T > MAXT) return false;
         if (fold)
             hipLaunchKernelGGL((pcgc_kernel<M, RPT, MAXT, true>), dim3(s->B), dim3(T), lds + (size_t)2 * s->N * NX * NX * sizeof(float), st, s->bf,
-                               s->N, s->B, s->p.max_pcg_iters, sqp_iter, write_p);
+                               s->N, s->B, s->p.max_pcg_iters, sqp_iter, write_p, 0.f);
         else
-            hipLaunchKernelGGL((pcgc_kernel<M, RPT, MAXT, false>), dim3(s->B), dim3(T), lds, st, s->bf, s->N, s->B, s->p.max_pcg_iters, sqp_iter, 0);
+            hipLaunchKernelGGL((pcgc_kernel<M, RPT, MAXT, false>), dim3(s->B), dim3(T), lds, st, s->bf, s->N, s->B, s->p.max_pcg_iters, sqp_iter, 0,
+                               0.f);
         return true;
+    }
+}
+
+// Schur complement formed inside the PCG kernel (pcgc_kernel<.., FUSE>): nx = 12 (3 rows per thread = the rows of one lane of a 4-lane
+// Schur group), the trajectory in <= 256 threads, stair fold available.  GATO_SCHUR_FUSED=0 (read when the solver is created) keeps
+// the two launches apart.
+template<class M> static bool schur_fused(const GatoSolver* s)
+{
+    constexpr int NX = 2 * M::NQ;
+    if constexpr (NX != 12) {
+        return false;
+    } else {
+        const int rows = s->N * s->nx;
+        const char* v = getenv("GATO_PCG_VARIANT");
+        if (v && atoi(v) != 100 && atoi(v) != 2) return false;
+        return s->fuse_schur && ((rows + 2) / 3 + 63) / 64 * 64 <= 256 && pcg_folds_stair<M>(s);
+    }
+}
+template<class M> static void launch_pcg_fused(GatoSolver* s, hipStream_t st, float dt, int sqp_iter)
+{
+    constexpr int NX = 2 * M::NQ;
+    if constexpr (NX == 12) {
+        const int rows = s->N * s->nx;
+        const int T = (((rows + 2) / 3 + 63) / 64) * 64;
+        const size_t lds = (size_t)(2 * s->vecp + 36) * sizeof(float) + (size_t)2 * s->N * NX * NX * sizeof(float);
+        hipLaunchKernelGGL((pcgc_kernel<M, 3, 512, true, true>), dim3(s->B), dim3(T), lds, st, s->bf, s->N, s->B, s->p.max_pcg_iters, sqp_iter, 0, dt);
     }
 }
 
@@ -317,11 +346,16 @@ template<class M> static int solve_impl(GatoSolver* s, float* d_xu, float dt, co
     mark(s, st, ST_MERIT, ei);
     const uint32_t iters = s->p.max_sqp_iters <= s->max_iters_alloc ? s->p.max_sqp_iters : s->max_iters_alloc;
     for (uint32_t it = 0; it < iters; it++) {
-        launch_kkt<M>(s, st, dt, (int)it);
+        const bool fused = schur_fused<M>(s);
+        launch_kkt<M>(s, st, dt, (int)it, fused ? 1 : 0);
         mark(s, st, ST_KKT, ei);
-        launch_schur<M>(s, st, dt);
-        mark(s, st, ST_SCHUR, ei);
-        launch_pcg<M>(s, st, (int)it);
+        if (fused) {
+            launch_pcg_fused<M>(s, st, dt, (int)it);
+        } else {
+            launch_schur<M>(s, st, dt);
+            mark(s, st, ST_SCHUR, ei);
+            launch_pcg<M>(s, st, (int)it);
+        }
         mark(s, st, ST_PCG, ei);
         if (step_fused(s)) {
             launch_step<M>(s, st, dt, (int)it);

@@ -17,9 +17,12 @@ ap.add_argument("-N", type=int, default=32)
 ap.add_argument("-B", type=int, default=1024)
 ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--reps", type=int, default=5)
+ap.add_argument("--max-pcg", type=int, default=-1)
 a = ap.parse_args()
 p = dict(DEFAULT_SOLVER_PARAMS)
 p["max_sqp_iters"] = a.iters
+if a.max_pcg >= 0:
+    p["max_pcg_iters"] = a.max_pcg
 pr = fig8_problem(a.plant, a.N, a.B)
 s = NativeSolver(a.plant, a.N, a.B, dt=0.01, **p)
 s.set_profiling(True)
