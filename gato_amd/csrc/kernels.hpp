@@ -1116,14 +1116,21 @@ GATO_DEV float wave_sum(float v)
 }
 
 // block-wide sum; `part` has 16 slots (unused ones zeroed once by the caller), read back with four 16-byte LDS loads
-GATO_DEV float block_sum(float v, float* part)
+// PARTS = 16-byte groups that can hold a wavefront's partial (<= 4 PARTS wavefronts in the workgroup): the skipped ones are exact
+// zeros, so every PARTS gives the same bits.
+template<int PARTS = 4> GATO_DEV float block_sum(float v, float* part)
 {
     v = wave_sum(v);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
     __syncthreads();
-    const float4 a = reinterpret_cast<const float4*>(part)[0], b = reinterpret_cast<const float4*>(part)[1];
+    const float4 a = reinterpret_cast<const float4*>(part)[0];
+    float r = (a.x + a.y) + (a.z + a.w);
+    if constexpr (PARTS == 1) return r;
+    const float4 b = reinterpret_cast<const float4*>(part)[1];
+    r = r + ((b.x + b.y) + (b.z + b.w));
+    if constexpr (PARTS == 2) return r;
     const float4 c = reinterpret_cast<const float4*>(part)[2], d = reinterpret_cast<const float4*>(part)[3];
-    return (((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w))) + (((c.x + c.y) + (c.z + c.w)) + ((d.x + d.y) + (d.z + d.w)));
+    return r + (((c.x + c.y) + (c.z + c.w)) + ((d.x + d.y) + (d.z + d.w)));
 }
 
 // RPT rows per thread; STREAM = false keeps the thread's S / P^-1 rows in registers, true re-reads them from global memory
@@ -1378,6 +1385,7 @@ template<class M, int RPT, int MAXT, bool FOLD, bool FUSE = false>
 __global__ __launch_bounds__(MAXT) void pcgc_kernel(Buffers bf, int N, int B, uint32_t max_iters, int sqp_iter, int write_p, float dt)
 {
     constexpr int NQ = M::NQ, NX = 2 * NQ, BR = 3 * NX, BROW = 3 * NX * NX;
+    constexpr int PARTS = (FUSE || MAXT <= 256) ? 1 : (MAXT <= 512 ? 2 : 4);  // FUSE is only launched with <= 256 threads
     static_assert(NX % RPT == 0, "rows of one thread must share a block row");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     if (bf.ctrl->done) return;
@@ -1581,7 +1589,7 @@ __global__ __launch_bounds__(MAXT) void pcgc_kernel(Buffers bf, int N, int B, ui
             pv[u] = zv[u];
             loc += rv[u] * zv[u];
         }
-        float rho = block_sum(loc, partA);
+        float rho = block_sum<PARTS>(loc, partA);
         if (!(fabsf(rho) < abs_tol)) {
             const float rho_init = fabsf(rho);
             for (uint32_t it = 0; it < max_iters; it++) {
@@ -1595,7 +1603,7 @@ __global__ __launch_bounds__(MAXT) void pcgc_kernel(Buffers bf, int N, int B, ui
                     if (!have) acc[u] = 0.f;
                     loc += pv[u] * acc[u];
                 }
-                const float pAp = block_sum(loc, partB);
+                const float pAp = block_sum<PARTS>(loc, partB);
                 const float alpha = rho / pAp;
 #pragma unroll
                 for (int u = 0; u < RPT; u++) {
@@ -1612,7 +1620,7 @@ __global__ __launch_bounds__(MAXT) void pcgc_kernel(Buffers bf, int N, int B, ui
                     zv[u] = have ? acc[u] : 0.f;
                     loc += rv[u] * zv[u];
                 }
-                const float rho_new = block_sum(loc, partA);
+                const float rho_new = block_sum<PARTS>(loc, partA);
                 if (fabsf(rho_new) < (abs_tol + eps * rho_init)) break;
                 const float beta = rho_new / rho;
                 rho = rho_new;
