@@ -25,24 +25,30 @@ HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md, chip-level 
 FP32_PEAK_TFLOPS = 157.3   # vector fp32 spec
 
 
-def stage_bytes(nq, N):
-    """Algorithmic HBM bytes per trajectory and launch of each kernel family (DESIGN.md section 'kernels'): compulsory reads + writes of the
-    buffers that cross the kernel boundary, each counted once."""
+def stage_bytes(nq, N, fused_schur, fused_step):
+    """Algorithmic HBM bytes per trajectory and launch of each kernel family: compulsory reads + writes of the
+    buffers that cross the kernel boundary, each buffer counted once per launch (re-reads by the lanes of one launch are cache hits)."""
     nx, nu = 2 * nq, nq
     traj = (nx + nu) * N - nu
-    kkt_blocks = (N - 1) * (3 * nq * nq + nq * nq + nq + nu + nx + nu + nx) + (nq * nq + nq + nx) + nx  # D,Qq,Qd,Rd,q,r,c (+terminal, c_0)
-    S = 3 * nx * nx * N
     vec = (N + 2) * nx
+    nD, nQq, nQd, nq_, nR, nr, nc = (N - 1) * 3 * nq * nq, N * nq * nq, N * nq, N * nx, (N - 1) * nu, (N - 1) * nu, N * nx
+    inv = nQq + nQd + nR                      # (Q + rho I)^-1 blocks, R^-1
+    lin = nD + inv + nq_ + nr + nc + 1        # what the Schur complement is formed from
+    row0 = 2 * nx * nx + nx                   # S / P^-1 main blocks of block row 0 and gamma_0
+    nS, nPd = (3 * N - 2) * nx * nx, N * nx * nx
     f = 4
-    return {
-        "kkt": f * (traj + 6 * N + 6 + nx + kkt_blocks),
-        "schur": f * (kkt_blocks + 1 + (N - 1) * (2 * nx * nx + nx * nx) + nx * nx * 2 + vec + N * (nq * nq + nq) + (N - 1) * nu      # schur: S rows, Pdiag, gamma, inverses
-                      + (N - 1) * (3 * nx * nx + 2 * nx * nx)),                                                                      # stair: 2 Pdiag + phi in, 2 blocks out
-        "pcg": f * (2 * S + 3 * vec + 2),
-        "dz": f * (2 * vec // 1 + (N - 1) * 3 * nq * nq + N * (nq * nq + nq + nx) + (N - 1) * 2 * nu + 2 * traj),
-        "merit": f * (8 * (2 * traj + 6 * N + nx + 6 + 2)),
-        "line_search": f * (3 * traj + 8 + 6),
+    dz_in = vec + nD + inv + nq_ + nr
+    merit_in = 2 * traj + 6 * N + nx + 6 + 1
+    out = {
+        "kkt": f * (traj + 6 * N + 6 + nx + 1 + nD + nQq + nQd + nq_ + nR + nr + nc + inv + (row0 if fused_schur else 0)),
+        "schur": 0 if fused_schur else f * (lin + nq * nq + nq + nS + nPd + vec),
+        "pcg": f * ((lin + row0 + vec + 2 + vec + 2) if fused_schur else (nS + nPd + 2 * vec + 2 + vec + 2)),
+        "dz": 0 if fused_step else f * (dz_in + traj + nq_ + nr),
+        "merit": f * ((dz_in + merit_in + traj + nq_ + nr + traj + 8 + 8) if fused_step else (merit_in + 8)),
+        "line_search": 0 if fused_step else f * (3 * traj + 8 + 6),
     }
+    out["merit1"] = f * (traj + 6 * N + nx + 6 + 1 + 1)  # the merit of the current iterate (first and last launch of a solve)
+    return out
 
 
 def usable_cores():
@@ -191,12 +197,19 @@ def main():
         return
 
     value = world * B * iters * a.steps / t
-    launches = {"kkt": iters, "schur": iters, "pcg": iters, "dz": iters, "merit": iters + 2, "line_search": iters}
-    per_launch_us = {k: stage_acc[k] / max(1, launches[k]) for k in launches}
+    fused_schur = stage_acc.get("schur", 0.0) == 0.0
+    fused_step = stage_acc.get("dz", 0.0) == 0.0
+    launches = {"kkt": iters, "schur": 0 if fused_schur else iters, "pcg": iters, "dz": 0 if fused_step else iters, "merit": iters + 2,
+                "line_search": 0 if fused_step else iters}
+    per_launch_us = {k: (stage_acc[k] / launches[k] if launches[k] else 0.0) for k in launches}
     dom = max(per_launch_us, key=lambda k: stage_acc[k])
-    sb = stage_bytes(NativeSolver_nq(plant), N)
-    dom_bytes = sb[dom] * B * (1.0 if dom != "merit" else (8 * iters + 2) / 8.0 / (iters + 2))
+    sb = stage_bytes(NativeSolver_nq(plant), N, fused_schur, fused_step)
+    if dom == "merit":   # iters step launches + 2 single merits share the stage clock
+        dom_bytes = (sb["merit"] * iters + sb["merit1"] * 2) / (iters + 2) * B
+    else:
+        dom_bytes = sb[dom] * B
     achieved = dom_bytes / (per_launch_us[dom] * 1e-6) / 1e9
+    iter_bytes = sum(sb[k] for k in ("kkt", "schur", "pcg", "dz", "merit", "line_search"))  # per trajectory and SQP iteration
     traffic = None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_summary.json")
     if os.path.exists(pmc_path):
@@ -216,8 +229,9 @@ def main():
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_us": per_launch_us[dom],
                      "stage_us_per_solve": {k: round(v, 1) for k, v in stage_acc.items()},
-                     "whole_iteration": {"algorithmic_bytes_per_traj_iter": 268e3 if (plant, N) == ("indy7", 32) else None,
-                                         "hbm_frac": (268e3 * value / world / 1e9 / HBM_PEAK_GBS) if (plant, N) == ("indy7", 32) else None}},
+                     "kernels_per_sqp_iteration": sum(1 for k in launches if launches[k] and k != "merit") + 1,
+                     "whole_iteration": {"algorithmic_bytes_per_traj_iter": iter_bytes,
+                                         "hbm_frac": iter_bytes * value / world / 1e9 / HBM_PEAK_GBS}},
         "solution_ok": ok,
     }
     if not a.no_cpu_baseline and world == 1:

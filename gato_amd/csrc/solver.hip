@@ -38,6 +38,7 @@ struct GatoSolver {
     Costs cw;
     int adapt_rho;
     int fuse_schur;  // Schur complement formed inside the PCG kernel (GATO_SCHUR_FUSED, default 1)
+    int fuse_step;   // dz + merit + line search in one launch (GATO_STEP_FUSED, default 1); both are read when the solver is created
     uint32_t max_iters_alloc;
     Buffers bf;
     float *d_xu_own, *d_xs_own, *d_ref_own, *d_merit_init0, *d_drho_init, *d_rho_init, *d_scratch_B;
@@ -98,6 +99,7 @@ extern "C" int gato_create(int plant, int N, int B, const GatoParams* params, Ga
     s->cw = Costs{params->q_cost, params->qd_cost, params->u_cost, params->N_cost, params->q_lim_cost, params->vel_lim_cost, params->ctrl_lim_cost};
     s->adapt_rho = 1;
     s->fuse_schur = getenv("GATO_SCHUR_FUSED") ? atoi(getenv("GATO_SCHUR_FUSED")) : 1;
+    s->fuse_step = getenv("GATO_STEP_FUSED") ? atoi(getenv("GATO_STEP_FUSED")) : 1;
     s->profiling = 0;
     s->last_stream = nullptr;
     memset(s->stage_us, 0, sizeof(s->stage_us));
@@ -297,8 +299,7 @@ template<class M> static void launch_dz(GatoSolver* s, hipStream_t st, float dt,
 // dz + merit(8 alphas) + line search in one launch: a workgroup of 8 N lanes per trajectory
 static bool step_fused(const GatoSolver* s)
 {
-    static const int on = getenv("GATO_STEP_FUSED") ? atoi(getenv("GATO_STEP_FUSED")) : 1;
-    return on && NUM_ALPHAS * s->N <= 512 && s->N <= 64;
+    return s->fuse_step && NUM_ALPHAS * s->N <= 512 && s->N <= 64;
 }
 template<class M> static void launch_step(GatoSolver* s, hipStream_t st, float dt, int sqp_iter)
 {

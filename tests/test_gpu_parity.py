@@ -229,6 +229,30 @@ def test_early_exit_on_device():
     assert np.all(r2["pcg_iters"] == 1) and r2["iters_done"] == 3
 
 
+@pytest.mark.parametrize("N,B,fstd", [(32, 24, 4.0), (64, 5, 0.0), (16, 7, 2.0)])
+def test_fused_kernels_equal_separate_launches(N, B, fstd, monkeypatch):
+    """The fused launches (Schur complement inside the PCG kernel, dz + merit + line search in one step kernel) run the SAME device
+    functions as the stand-alone kernels the stage tests pin against the oracle, so whole solves must agree bit for bit."""
+    from gato_amd._lib import NativeSolver
+    p = dict(DEFAULT_SOLVER_PARAMS)
+    p["max_sqp_iters"] = 4
+    pr = fig8_problem("indy7", N, B, f_ext_std=fstd)
+    out = {}
+    for tag, env in (("fused", {}), ("separate", {"GATO_SCHUR_FUSED": "0", "GATO_STEP_FUSED": "0"})):
+        for k in ("GATO_SCHUR_FUSED", "GATO_STEP_FUSED"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        s = NativeSolver("indy7", N, B, dt=DT, **p)   # the switches are read when the solver is created
+        s.set_f_ext_batch(pr["f_ext"])
+        out[tag] = s.solve(pr["xu"], DT, pr["x_s"], pr["ref"])
+    f, g = out["fused"], out["separate"]
+    np.testing.assert_array_equal(f["pcg_iters_all"], g["pcg_iters_all"])
+    np.testing.assert_array_equal(f["ls_step_size"], g["ls_step_size"])
+    np.testing.assert_array_equal(f["XU"], g["XU"])
+    np.testing.assert_array_equal(f["final_merit"], g["final_merit"])
+
+
 def test_sim_forward_and_ee_pos():
     from oracle import oracle as O
     nat, orc, pr = make("iiwa14", 8, 5, 4.0)
