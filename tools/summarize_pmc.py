@@ -15,7 +15,7 @@ import sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-STAGE = [("pcg", r"pcgc?_kernel"), ("kkt", r"kkt_kernel"), ("schur", r"schur2?_kernel|pinv_kernel"), ("merit", r"merit_kernel"), ("dz", r"dz_kernel"),
+STAGE = [("pcg", r"pcgc?_kernel"), ("kkt", r"kkt_kernel"), ("schur", r"schur[2q]?_kernel|pinv_kernel"), ("merit", r"merit_kernel|step_kernel"), ("dz", r"dz_kernel"),
          ("line_search", r"line_search_kernel")]
 
 
@@ -35,6 +35,7 @@ def main(tag):
     out = {}
     fetch = load(os.path.join(ROOT, "gpurun_out", "pmc_%s_FETCH_SIZE" % tag), "FETCH_SIZE")
     write = load(os.path.join(ROOT, "gpurun_out", "pmc_%s_WRITE_SIZE" % tag), "WRITE_SIZE")
+    n_iter = sum(v[1] for k, v in fetch.items() if re.search(r"kkt_kernel", k))  # one assembly launch per SQP iteration
     for stage, pat in STAGE:
         fk = sum(v[0] for k, v in fetch.items() if re.search(pat, k))
         fn = sum(v[1] for k, v in fetch.items() if re.search(pat, k))
@@ -42,11 +43,11 @@ def main(tag):
         wn = sum(v[1] for k, v in write.items() if re.search(pat, k))
         if not fn or not wn:
             continue
-        per_f = fk / fn * 1024.0
-        per_w = wk / wn * 1024.0
-        if stage == "schur":  # two kernels per launch of the family
-            per_f *= 2
-            per_w *= 2
+        # a "launch" of a family = everything it runs in one SQP iteration (the merit family: per dispatch, like bench.py's clock)
+        launches_f = fn if stage == "merit" else n_iter
+        launches_w = wn if stage == "merit" else sum(v[1] for k, v in write.items() if re.search(r"kkt_kernel", k))
+        per_f = fk / launches_f * 1024.0
+        per_w = wk / launches_w * 1024.0
         out[stage] = {"fetch_bytes_raw_per_launch": per_f, "write_bytes_per_launch": per_w,
                       "hbm_bytes_per_launch": 2.0 * per_f + per_w, "hbm_bytes_per_launch_lower": per_f + per_w, "dispatches": fn}
     out["_note"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), KiB -> bytes, read side doubled per the gfx950 correction; bench.py at C2 (indy7 N=32 B=1024)"
