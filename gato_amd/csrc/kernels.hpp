@@ -381,14 +381,12 @@ template<int n, bool THREE> GATO_DEV void gj_inverse(float* Mat)
     }
 }
 
-// Column-split assembly.  Wavefronts with blockIdx.y = g < G compute, for 64 (b,k) problems, forward dynamics and the derivative
-// columns of group g (d qdd / d q_J, d qdd / d qd_J, M^-1[:, J]); the group with column 0 also stores the defect c_{k+1}.  The common
-// prefix (M^-1, two RNEA passes, 3.7 k instructions) is recomputed per group; each column adds 1.3 k.
-// blockIdx.y = G: cost blocks of knot k (and the terminal ones for k = N-2), their inverses (Q_k + rho I_q)^-1, R_k^-1 -- the
-// arithmetic of the 3-matrix Gauss-Jordan of schur_linsys.cuh:96 -- and c_0 = x_0 - x_s (lane k = N-1).
-// NOT inlined on purpose: with G tasks inlined into one kernel the code object grows past the +-128 KB reach of s_cbranch
-// (325 KB for iiwa14, G = 7) and the compiler's long-branch relaxation produced wrong results on gfx950 / ROCm 7.2 (columns of D
-// corrupted when f_ext != 0; caught by tests/test_gpu_parity.py).  As real functions every task body stays below 64 KB and is
+// One derivative-column task of the assembly kernel (see kkt_kernel): forward dynamics, then columns JA and JB of
+// [d qdd / d q | d qdd / d qd | M^-1]; the task with column 0 also stores the defect c_{k+1}.  The common prefix (M^-1, two RNEA
+// passes, 3.7 k instructions) is recomputed per task.
+// NOT inlined on purpose: with every task inlined into one kernel the code object grows past the +-128 KB reach of s_cbranch
+// (325 KB for iiwa14 with 7 tasks) and the compiler's long-branch relaxation produced wrong results on gfx950 / ROCm 7.2 (columns of
+// D corrupted when f_ext != 0; caught by tests/test_gpu_parity.py).  As real functions every task body stays below 64 KB and is
 // reached through s_swappc.  not_tail_called: a call marked `tail` disables the no-callee-saved-registers optimisation and the task
 // would open with ~110 scratch stores of caller registers nobody needs.
 template<class M, int JA, int JB>
@@ -530,7 +528,7 @@ __global__ __launch_bounds__(64, 2) void kkt_kernel(Buffers bf, Costs cw, int N,
 }
 
 // =========================================================================================================================
-// Schur complement formation (schur_linsys.cuh:14-211), one lane per (b,k).
+// Schur complement formation (schur_linsys.cuh:14-211)
 // =========================================================================================================================
 // the Q_0 row (schur_linsys.cuh:166-210) of trajectory b, by one lane
 template<class M>
@@ -599,124 +597,6 @@ GATO_DEV void schur_row0(const Buffers& bf, int N, int b, float rho, float* S, f
     load_vec<NX, NX>(q0, bf.q + b0 * NX);
     load_vec<NX, NX>(c0, bf.c + b0 * NX);
     schur_row0_regs<M>(Qq, Qd, q0, c0, rho, S, P, gam);
-}
-
-template<class M>
-__global__ __launch_bounds__(64) void schur_kernel(Buffers bf, int N, int B, float dt)
-{
-    constexpr int NQ = M::NQ, NX = 2 * NQ, NU = NQ, BR = 3 * NX, BROW = 3 * NX * NX;
-    if (bf.ctrl->done) return;
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    const int k = g % N, b = g / N;
-    if (b >= B) return;
-    const size_t bk = (size_t)b * N + k;
-    const float rho = bf.rho[b];
-    float* S = bf.S + (size_t)b * N * BROW;
-    float* P = bf.Pinv + (size_t)b * N * BROW;
-    float* gam = bf.gamma + (size_t)b * (N + 2) * NX;
-
-    if (k == N - 1) {
-        schur_row0<M>(bf, N, b, rho, S, P, gam);
-        return;
-    }
-
-    // ---- k <= N-2: (Q_k + rho I_q)^-1, (Q_{k+1} + rho I_q)^-1 and R_k^-1 were produced by the assembly kernel's cost wave
-    float Qi[NQ * NQ], Qi1[NQ * NQ], di[NQ], di1[NQ], ri[NU];
-    load_vec<NQ * NQ, NQ * NQ>(Qi, bf.Qqi + bk * NQ * NQ);
-    load_vec<NQ, NQ>(di, bf.Qdi + bk * NQ);
-    load_vec<NQ * NQ, NQ * NQ>(Qi1, bf.Qqi + (bk + 1) * NQ * NQ);
-    load_vec<NQ, NQ>(di1, bf.Qdi + (bk + 1) * NQ);
-    load_vec<NU, NU>(ri, bf.Rdi + bk * NU);
-
-    float Dm[3 * NQ * NQ];
-    load_vec<3 * NQ * NQ, 3 * NQ * NQ>(Dm, bf.D + bk * 3 * NQ * NQ);
-    const float h2 = half_dt_sq(dt);
-    // A (row-major here: Ar[r][c]) and B reconstructed from D
-    float phi[NX][NX];  // phi = A Qinv, [row][col]
-    float theta[NX][NX];
-    {
-        float A[NX][NX], Bm[NX][NU];
-#pragma unroll
-        for (int r = 0; r < NX; r++) {
-#pragma unroll
-            for (int c = 0; c < NX; c++) A[r][c] = A_elem<NQ>(Dm, r, c, dt, h2);
-#pragma unroll
-            for (int c = 0; c < NU; c++) Bm[r][c] = B_elem<NQ>(Dm, r, c, dt, h2);
-        }
-#pragma unroll
-        for (int r = 0; r < NX; r++) {
-#pragma unroll
-            for (int c = 0; c < NQ; c++) {
-                float s = 0.f;
-#pragma unroll
-                for (int j = 0; j < NQ; j++) s += A[r][j] * Qi[c * NQ + j];
-                phi[r][c] = s;
-                phi[r][NQ + c] = A[r][NQ + c] * di[c];
-            }
-        }
-        // theta = Qinv_{k+1} + phi A^T + (B Rinv) B^T
-#pragma unroll
-        for (int y = 0; y < NX; y++)
-#pragma unroll
-            for (int x = 0; x < NX; x++) {
-                float s = 0.f, s2 = 0.f;
-#pragma unroll
-                for (int j = 0; j < NX; j++) s += phi[y][j] * A[x][j];
-#pragma unroll
-                for (int j = 0; j < NU; j++) s2 += (Bm[y][j] * ri[j]) * Bm[x][j];
-                float t = 0.f;
-                if (y < NQ && x < NQ) t = Qi1[x * NQ + y];
-                else if (x == y) t = di1[y - NQ];
-                t += s;
-                t += s2;
-                theta[y][x] = t;
-            }
-        // gamma_{k+1} = c_{k+1} - Qinv_{k+1} q_{k+1} + phi q_k + B Rinv r_k
-        float qk[NX], qk1[NX], rk[NU], ck1[NX], gg[NX];
-        load_vec<NX, NX>(qk, bf.q + bk * NX);
-        load_vec<NX, NX>(qk1, bf.q + (bk + 1) * NX);
-        load_vec<NU, NU>(rk, bf.r + bk * NU);
-        load_vec<NX, NX>(ck1, bf.c + (bk + 1) * NX);
-#pragma unroll
-        for (int y = 0; y < NX; y++) {
-            float g1 = -1.0f * ck1[y];
-            float s = 0.f;
-            if (y < NQ) {
-#pragma unroll
-                for (int j = 0; j < NQ; j++) s += Qi1[j * NQ + y] * qk1[j];
-            } else {
-                s = di1[y - NQ] * qk1[y];
-            }
-            g1 += s;
-            s = 0.f;
-#pragma unroll
-            for (int j = 0; j < NX; j++) s += phi[y][j] * qk[j];
-            g1 += -s;
-            s = 0.f;
-#pragma unroll
-            for (int j = 0; j < NU; j++) s += (Bm[y][j] * ri[j]) * rk[j];
-            g1 += -s;
-            gg[y] = -1.0f * g1;
-        }
-        store_vec<NX, NX>(gam + (size_t)(k + 2) * NX, gg);
-    }
-    // S: row k right = phi^T, row k+1 left = phi, row k+1 main = -theta
-    {
-        float* Sk = S + (size_t)k * BROW;
-        float* Sk1 = S + (size_t)(k + 1) * BROW;
-#pragma unroll
-        for (int y = 0; y < NX; y++) {
-            float row[2 * NX], rt[NX];
-#pragma unroll
-            for (int x = 0; x < NX; x++) {
-                row[x] = phi[y][x];
-                row[NX + x] = -theta[y][x];
-                rt[x] = phi[x][y];
-            }
-            store_vec<2 * NX, NX>(Sk1 + y * BR, row);
-            store_vec<NX, NX>(Sk + y * BR + 2 * NX, rt);
-        }
-    }
 }
 
 // ---- cooperative form: LPP lanes per (b,k) ------------------------------------------------------------------------------------
@@ -982,40 +862,6 @@ __global__ __launch_bounds__(256) void schurq_kernel(Buffers bf, int N, int B, f
             for (int x = 0; x < NX; x++) row[x] = -th[i][x];
             store_vec<NX, NX>(Pk1 + (size_t)(y0 + i) * BR + NX, row);
         }
-    }
-}
-
-// P^-1 main diagonal blocks (schur_linsys.cuh:150-164): row k+1 = -(theta_k + rho I_q)^-1 by the 1-matrix Gauss-Jordan.  Its own
-// launch: theta_k is read back from S (row k+1 main = -theta_k, an exact negation), so the 12 k-instruction chain of the fused form
-// becomes two chains of ~5 k and ~2.5 k instructions that each fit a wavefront's registers far better.  One lane per (b, k >= 1).
-template<class M>
-__global__ __launch_bounds__(64) void pinv_kernel(Buffers bf, int N, int B)
-{
-    constexpr int NQ = M::NQ, NX = 2 * NQ, BR = 3 * NX, BROW = 3 * NX * NX;
-    if (bf.ctrl->done) return;
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    const int k = g % N, b = g / N;
-    if (b >= B || k == 0) return;
-    const float rho = bf.rho[b];
-    const float* Sk = bf.S + ((size_t)b * N + k) * BROW;
-    float* Pk = bf.Pinv + ((size_t)b * N + k) * BROW;
-    float W[NX * NX];
-#pragma unroll
-    for (int y = 0; y < NX; y++) {
-        float row[NX];
-        load_vec<NX, NX>(row, Sk + y * BR + NX);
-#pragma unroll
-        for (int x = 0; x < NX; x++) W[x * NX + y] = -row[x];
-    }
-#pragma unroll
-    for (int i = 0; i < NQ; i++) W[i * NX + i] += rho;
-    gj_inverse<NX, false>(W);
-#pragma unroll
-    for (int y = 0; y < NX; y++) {
-        float row[NX];
-#pragma unroll
-        for (int x = 0; x < NX; x++) row[x] = -W[x * NX + y];
-        store_vec<NX, NX>(Pk + y * BR + NX, row);
     }
 }
 

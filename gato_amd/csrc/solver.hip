@@ -174,20 +174,11 @@ template<class M> static void launch_kkt(GatoSolver* s, hipStream_t st, float dt
 template<class M> static bool pcg_folds_stair(const GatoSolver* s);
 template<class M> static void launch_schur(GatoSolver* s, hipStream_t st, float dt, bool force_stair = false)
 {
-    // A 16-lanes-per-problem cooperative variant of these kernels (lane = column of phi / theta / the Gauss-Jordan tableau, inputs staged
-    // in LDS, pivot columns by ds_bpermute) was built and measured in round 1: bit-compatible, but 2.6 k instructions per lane x 8192
-    // wavefronts = 5x the wave-instructions of the lane-per-problem form and 90 us vs 70 us at C2 -- removed again.
+    // lanes per (b,k): 4 with rows 3l..3l+2 (indy7); nq odd (iiwa14) divides evenly only into 2 x 7 rows -- heavier on registers
+    // (AGPR moves, a few spills) but still ahead of a lane-per-knot kernel pair: 185 vs 238 us per launch at C3
     const long probs = (long)s->B * s->N;
-    static const int coop = getenv("GATO_SCHUR_COOP") ? atoi(getenv("GATO_SCHUR_COOP")) : 1;
-    if (coop) {
-        // lanes per (b,k): 4 with rows 3l..3l+2 (indy7); nq odd (iiwa14) divides evenly only into 2 x 7 rows -- heavier on registers
-        // (AGPR moves, a few spills) but still ahead of the lane-per-knot pair below: 185 vs 238 us per launch at C3
-        constexpr int LPP = (M::NQ % 2 == 0) ? 4 : 2;
-        hipLaunchKernelGGL((schurq_kernel<M, LPP>), dim3(cdiv(probs * LPP, 256), 2), dim3(256), 0, st, s->bf, s->N, s->B, dt);
-    } else {
-        hipLaunchKernelGGL((schur_kernel<M>), dim3(cdiv(probs, 64)), dim3(64), 0, st, s->bf, s->N, s->B, dt);
-        hipLaunchKernelGGL((pinv_kernel<M>), dim3(cdiv(probs, 64)), dim3(64), 0, st, s->bf, s->N, s->B);
-    }
+    constexpr int LPP = (M::NQ % 2 == 0) ? 4 : 2;
+    hipLaunchKernelGGL((schurq_kernel<M, LPP>), dim3(cdiv(probs * LPP, 256), 2), dim3(256), 0, st, s->bf, s->N, s->B, dt);
     if (force_stair || !pcg_folds_stair<M>(s)) hipLaunchKernelGGL((schur2_kernel<M>), dim3(cdiv(probs, 64)), dim3(64), 0, st, s->bf, s->N, s->B);
 }
 static int g_pcg_variant = -1;  // test / tuning override (GATO_PCG_VARIANT): 0 strided rows, 1 RPT=6, 2 RPT=3, 3 RPT=2
