@@ -226,7 +226,10 @@ template<class M> static void launch_pcg_fused(GatoSolver* s, hipStream_t st, fl
     if constexpr (NX == 12) {
         const int rows = s->N * s->nx;
         const int T = (((rows + 2) / 3 + 63) / 64) * 64;
-        const size_t lds = (size_t)(2 * s->vecp + 36) * sizeof(float) + (size_t)2 * s->N * NX * NX * sizeof(float);
+        // LDS behind the vectors: the two fold buffers [N][nx][nx], later reused to park 3 x nx/4 float4 per thread (the larger for N < 8,
+        // where the workgroup is padded to one wavefront)
+        const size_t fold = (size_t)2 * s->N * NX * NX * sizeof(float), park = (size_t)3 * (NX / 4) * T * 4 * sizeof(float);
+        const size_t lds = (size_t)(2 * s->vecp + 36) * sizeof(float) + (fold > park ? fold : park);
         hipLaunchKernelGGL((pcgc_kernel<M, 3, 512, true, true>), dim3(s->B), dim3(T), lds, st, s->bf, s->N, s->B, s->p.max_pcg_iters, sqp_iter, 0, dt);
     }
 }

@@ -167,7 +167,7 @@ def test_iterate_parity_tight_pcg(plant, N, B):
     assert relscale(rg["initial_merit"], ro["initial_merit"]) < 1e-5
 
 
-@pytest.mark.parametrize("plant,N,B,fstd", [("indy7", 32, 32, 0.0), ("iiwa14", 16, 8, 3.0)])
+@pytest.mark.parametrize("plant,N,B,fstd", [("indy7", 32, 32, 0.0), ("iiwa14", 16, 8, 3.0), ("indy7", 4, 4, 1.0)])
 def test_full_solve_parity(plant, N, B, fstd):
     nat, orc, pr = make(plant, N, B, fstd, max_sqp_iters=3)
     rg = nat.solve(pr["xu"], DT, pr["x_s"], pr["ref"])
@@ -229,7 +229,7 @@ def test_early_exit_on_device():
     assert np.all(r2["pcg_iters"] == 1) and r2["iters_done"] == 3
 
 
-@pytest.mark.parametrize("N,B,fstd", [(32, 24, 4.0), (64, 5, 0.0), (16, 7, 2.0)])
+@pytest.mark.parametrize("N,B,fstd", [(32, 24, 4.0), (64, 5, 0.0), (16, 7, 2.0), (4, 3, 1.0), (8, 2, 0.0)])
 def test_fused_kernels_equal_separate_launches(N, B, fstd, monkeypatch):
     """The fused launches (Schur complement inside the PCG kernel, dz + merit + line search in one step kernel) run the SAME device
     functions as the stand-alone kernels the stage tests pin against the oracle, so whole solves must agree bit for bit."""
