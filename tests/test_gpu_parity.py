@@ -253,6 +253,32 @@ def test_fused_kernels_equal_separate_launches(N, B, fstd, monkeypatch):
     np.testing.assert_array_equal(f["final_merit"], g["final_merit"])
 
 
+@pytest.mark.parametrize("plant,N,B,shard", [("iiwa14", 64, 4, 1), ("indy7", 32, 6, 5)])
+def test_hparam_sweep_settings_parity(plant, N, B, shard):
+    """Configuration C5's settings: dt = 0.05, mu = 1, pcg_tol 1e-3, a cost tuple of the sweep grid, per-trajectory rho
+    over nine decades, constant goal: the first SQP iteration must take the oracle's decisions, and iterates agree."""
+    from gato_amd._lib import NativeSolver
+    from gato_amd.bsqp.workloads import hparam_problem
+    from oracle.oracle import OracleSolver
+    pr = hparam_problem(plant, N, B, shard=shard)
+    p = dict(pr["params"], max_sqp_iters=1, pcg_tol=1e-7, max_pcg_iters=1000)
+    nat = NativeSolver(plant, N, B, dt=pr["dt"], **p)
+    orc = OracleSolver(plant, N, B, dt=pr["dt"], **p)
+    for s in (nat, orc):
+        s.set_rho_penalty_batch(pr["rho"])
+    rg = nat.solve(pr["xu"], pr["dt"], pr["x_s"], pr["ref"])
+    ro = orc.solve(pr["xu"], pr["dt"], pr["x_s"], pr["ref"])
+    np.testing.assert_array_equal(rg["ls_step_size"], ro["ls_step_size"])
+    assert rel(rg["initial_merit"], ro["initial_merit"]) < 1e-5
+    # rho spans 1e-8 .. 1e1 in this sweep: with rho ~ 1e-8 the Gauss-Jordan inverses lose digits (no pivoting), hence 2e-3
+    assert traj_err(rg["XU"], ro["XU"]).max() < 2e-3, traj_err(rg["XU"], ro["XU"])
+    p5 = dict(pr["params"], max_sqp_iters=5)
+    nat5 = NativeSolver(plant, N, B, dt=pr["dt"], **p5)
+    nat5.set_rho_penalty_batch(pr["rho"])
+    r5 = nat5.solve(pr["xu"], pr["dt"], pr["x_s"], pr["ref"])
+    assert np.all(np.isfinite(r5["XU"])) and np.all(r5["final_merit"] <= r5["initial_merit"])
+
+
 def test_sim_forward_and_ee_pos():
     from oracle import oracle as O
     nat, orc, pr = make("iiwa14", 8, 5, 4.0)

@@ -48,3 +48,32 @@ def test_fig8_problem_shapes_and_sharding():
     assert not np.array_equal(pr["ref"][0], pr["ref"][1])
     pi = fig8_problem("iiwa14", 16, 2, f_ext_std=5.0)
     assert pi["xu"].shape == (2, 21 * 16 - 7) and np.abs(pi["f_ext"]).max() > 0
+
+
+def test_hparam_problem_c5():
+    """C5: per-shard cost tuple, per-trajectory rho on a log grid, constant goal, zero start."""
+    from gato_amd.bsqp.workloads import HPARAM_COST_GRID, hparam_problem
+    assert len(HPARAM_COST_GRID) == 24 and HPARAM_COST_GRID[0] == dict(q_cost=10.0, qd_cost=1e-1, u_cost=1e-6, N_cost=100.0)
+    a = hparam_problem("iiwa14", 64, 6, shard=3)
+    b = hparam_problem("iiwa14", 64, 6, shard=3)
+    c = hparam_problem("iiwa14", 64, 6, shard=4)
+    assert a["xu"].shape == (6, 21 * 64 - 7) and a["ref"].shape == (6, 6 * 64) and a["dt"] == 0.05
+    np.testing.assert_array_equal(a["ref"], b["ref"])
+    assert not np.array_equal(a["ref"], c["ref"]) and a["params"]["qd_cost"] != c["params"]["qd_cost"] or a["params"] != c["params"]
+    r = a["ref"].reshape(6, 64, 6)
+    assert np.all(r[:, :, :3] == r[:, :1, :3]) and np.all(r[:, :, 3:] == 0) and np.all(a["x_s"] == 0) and np.all(a["xu"] == 0)
+    assert np.all(np.abs(r[:, 0, :2]) <= 0.8) and np.all((r[:, 0, 2] >= 0.2) & (r[:, 0, 2] <= 0.8))
+    np.testing.assert_allclose(a["rho"], 10.0 ** (-8 + 9 * (np.arange(6) + 1) / 513.0), rtol=1e-6)
+    assert a["params"]["mu"] == 1.0 and a["params"]["pcg_tol"] == 1e-3 and a["params"]["max_sqp_iters"] == 10
+
+
+def test_oracle_solves_hparam_problem():
+    """The C5 settings drive the oracle end to end (dt = 0.05, mu = 1, per-trajectory rho, other cost weights)."""
+    from gato_amd.bsqp.workloads import hparam_problem
+    from oracle.oracle import OracleSolver
+    pr = hparam_problem("iiwa14", 16, 3, shard=1)
+    p = dict(pr["params"], max_sqp_iters=3)
+    o = OracleSolver("iiwa14", 16, 3, dt=pr["dt"], **p)
+    o.set_rho_penalty_batch(pr["rho"])
+    r = o.solve(pr["xu"], pr["dt"], pr["x_s"], pr["ref"])
+    assert np.all(np.isfinite(r["XU"])) and np.all(r["final_merit"] <= r["initial_merit"])
