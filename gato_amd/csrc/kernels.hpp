@@ -108,6 +108,28 @@ GATO_DEV float joint_barrier_hess(float q, float lo, float hi)
     return 1.0f / (amin * amin) + 1.0f / (amax * amax);
 }
 
+// GLOBAL memory only: 16-byte accesses at 4-byte alignment (legal for global_load/store_dwordx4 on gfx950; LDS needs natural
+// alignment, so the ALIGN-aware helpers below stay in charge there).  nq = 7 gives every per-knot block an odd float count, and
+// with the aligned helpers all of iiwa14's block traffic was single-dword instructions.
+struct __attribute__((packed, aligned(4))) F4U { float x, y, z, w; };
+template<int CNT> GATO_DEV void gload_vec(float* dst, const float* __restrict__ src)
+{
+#pragma unroll
+    for (int i = 0; i < CNT / 4; i++) {
+        const F4U v = reinterpret_cast<const F4U*>(src)[i];
+        dst[4 * i] = v.x; dst[4 * i + 1] = v.y; dst[4 * i + 2] = v.z; dst[4 * i + 3] = v.w;
+    }
+#pragma unroll
+    for (int i = CNT / 4 * 4; i < CNT; i++) dst[i] = src[i];
+}
+template<int CNT> GATO_DEV void gstore_vec(float* __restrict__ dst, const float* src)
+{
+#pragma unroll
+    for (int i = 0; i < CNT / 4; i++) reinterpret_cast<F4U*>(dst)[i] = F4U{src[4 * i], src[4 * i + 1], src[4 * i + 2], src[4 * i + 3]};
+#pragma unroll
+    for (int i = CNT / 4 * 4; i < CNT; i++) dst[i] = src[i];
+}
+
 // vectorised private<->global copies.  ALIGN = a number of floats that divides every offset the pointer can take (and the
 // allocation itself is 256-byte aligned), so the widest access that is BOTH naturally aligned and divides CNT is used.
 template<int CNT, int ALIGN> constexpr int vec_width()
@@ -861,6 +883,169 @@ __global__ __launch_bounds__(256) void schurq_kernel(Buffers bf, int N, int B, f
 #pragma unroll
             for (int x = 0; x < NX; x++) row[x] = -th[i][x];
             store_vec<NX, NX>(Pk1 + (size_t)(y0 + i) * BR + NX, row);
+        }
+    }
+}
+
+// ---- one ROW per lane: groups of 16 lanes (nx of them active) per (b,k) ----------------------------------------------------------
+// For nx = 14 (iiwa14) the 4-lane split does not exist and 2 lanes x 7 rows need ~400 registers.  Here lane l < nx owns row l of
+// phi_k, theta_k and (theta_k + rho I_q)^-1: ~200 registers, 16 x the wavefronts of a lane-per-knot kernel.  Row-dependent inputs
+// (the lane's row of A, B, Q_{k+1}^-1) are fetched with lane-dependent ADDRESSES, everything else is loaded identically by the
+// group (one request).  The pivot row of each elimination step is broadcast inside the group with ds_bpermute (__shfl, width 16).
+template<class M>
+__global__ __launch_bounds__(256) void schur1_kernel(Buffers bf, int N, int B, float dt)
+{
+    constexpr int NQ = M::NQ, NX = 2 * NQ, NU = NQ, BR = 3 * NX, BROW = 3 * NX * NX;
+    static_assert(NX <= 16, "one group of 16 lanes per knot");
+    if (bf.ctrl->done) return;
+    if (blockIdx.y == 1) {  // the Q_0 rows: one lane per trajectory
+        const int b = blockIdx.x * blockDim.x + threadIdx.x;
+        if (b >= B) return;
+        schur_row0<M>(bf, N, b, bf.rho[b], bf.S + (size_t)b * N * BROW, bf.Pinv + (size_t)b * N * BROW, bf.gamma + (size_t)b * (N + 2) * NX);
+        return;
+    }
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    const int l = threadIdx.x & 15;
+    const int pidx = g >> 4;
+    const int k = pidx % N, b = pidx / N;
+    if (b >= B || k == N - 1) return;  // whole groups are in or out
+    const bool act = l < NX;
+    const int y = act ? l : 0;         // the 16 - nx spare lanes shadow row 0 and store nothing
+    const bool upper = y < NQ;         // row in the q half
+    const int rm = upper ? y : y - NQ;
+    const size_t bk = (size_t)b * N + k;
+    const float h2 = half_dt_sq(dt);
+    const float coef = upper ? h2 : dt;
+    const float* Dg = bf.D + bk * 3 * NQ * NQ;
+
+    float Ar[NX], Bri[NU], phi[NX], th[NX], gg;
+    {
+        // own row of A_k (A_elem with a lane-dependent row) and of B_k R_k^-1
+        float ri[NU];
+        gload_vec<NU>(ri, bf.Rdi + bk * NU);
+#pragma unroll
+        for (int c = 0; c < NX; c++) {
+            const float d = Dg[c * NQ + rm];
+            float v0 = (c == y) ? 1.0f : 0.f;
+            if (c >= NQ) v0 = (upper && c - NQ == y) ? dt : v0;
+            Ar[c] = v0 + coef * d;
+        }
+#pragma unroll
+        for (int c = 0; c < NU; c++) Bri[c] = (coef * Dg[2 * NQ * NQ + c * NQ + rm]) * ri[c];
+    }
+    if (opaque_true()) {
+        float Qi[NQ * NQ], di[NQ];
+        gload_vec<NQ * NQ>(Qi, bf.Qqi + bk * NQ * NQ);
+        gload_vec<NQ>(di, bf.Qdi + bk * NQ);
+#pragma unroll
+        for (int c = 0; c < NQ; c++) {
+            float sacc = 0.f;
+#pragma unroll
+            for (int j = 0; j < NQ; j++) sacc += Ar[j] * Qi[c * NQ + j];
+            phi[c] = sacc;
+            phi[NQ + c] = Ar[NQ + c] * di[c];
+        }
+    }
+    // own row of Q_{k+1}^-1: tq (q half, zero in qd-half lanes) and the single diagonal entry td (qd half)
+    float tq[NQ], td;
+    {
+        const float* Q1 = bf.Qqi + (bk + 1) * NQ * NQ;
+#pragma unroll
+        for (int x = 0; x < NQ; x++) {
+            const float v = Q1[x * NQ + rm];
+            tq[x] = upper ? v : 0.f;
+        }
+        const float dv = bf.Qdi[(bk + 1) * NQ + rm];
+        td = upper ? 0.f : dv;
+    }
+    if (opaque_true()) {
+        float Dm[3 * NQ * NQ];
+        gload_vec<3 * NQ * NQ>(Dm, Dg);
+#pragma unroll
+        for (int x = 0; x < NX; x++) {
+            float sacc = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < NX; j++) sacc += phi[j] * A_elem<NQ>(Dm, x, j, dt, h2);
+#pragma unroll
+            for (int j = 0; j < NU; j++) s2 += Bri[j] * B_elem<NQ>(Dm, x, j, dt, h2);
+            float t;
+            if (x < NQ) t = tq[x];
+            else t = (x - NQ == rm) ? td : 0.f;
+            t += sacc;
+            t += s2;
+            th[x] = t;
+        }
+    }
+    if (opaque_true()) {
+        float qk[NX], qk1[NX], rk[NU];
+        gload_vec<NX>(qk, bf.q + bk * NX);
+        gload_vec<NX>(qk1, bf.q + (bk + 1) * NX);
+        gload_vec<NU>(rk, bf.r + bk * NU);
+        const float cy = bf.c[(bk + 1) * NX + y], qy = bf.q[(bk + 1) * NX + y];
+        float g1 = -1.0f * cy;
+        float sq = 0.f;
+#pragma unroll
+        for (int j = 0; j < NQ; j++) sq += tq[j] * qk1[j];
+        const float sd = td * qy;
+        g1 += upper ? sq : sd;
+        float sacc = 0.f;
+#pragma unroll
+        for (int j = 0; j < NX; j++) sacc += phi[j] * qk[j];
+        g1 += -sacc;
+        sacc = 0.f;
+#pragma unroll
+        for (int j = 0; j < NU; j++) sacc += Bri[j] * rk[j];
+        g1 += -sacc;
+        gg = -1.0f * g1;
+    }
+    float* S = bf.S + (size_t)b * N * BROW;
+    if (act) {
+        float* Sk = S + (size_t)k * BROW;
+        float* Sk1 = S + (size_t)(k + 1) * BROW;
+        float row[2 * NX];
+#pragma unroll
+        for (int x = 0; x < NX; x++) {
+            row[x] = phi[x];
+            row[NX + x] = -th[x];
+        }
+        gstore_vec<2 * NX>(Sk1 + (size_t)y * BR, row);
+#pragma unroll
+        for (int x = 0; x < NX; x++) Sk[(size_t)x * BR + 2 * NX + y] = phi[x];  // right block of row k = phi^T
+        bf.gamma[(size_t)b * (N + 2) * NX + (size_t)(k + 2) * NX + y] = gg;
+    }
+    // (theta_k + rho I_q)^-1 by Gauss-Jordan across the group (schur_linsys.cuh:150-164)
+    {
+        const float rho = bf.rho[b];
+#pragma unroll
+        for (int c = 0; c < NQ; c++) th[c] += (c == y) ? rho : 0.f;  // first nq diagonal entries (only rows y < nq have c == y there)
+#pragma unroll
+        for (int p = 0; p < NX; p++) {
+            float prow[NX];
+#pragma unroll
+            for (int c = 0; c < NX; c++) prow[c] = __shfl(th[c], p, 16);
+            const float pvInv = 1.0f / prow[p];
+            const float f = th[p] * pvInv;
+            const bool owner = (y == p);
+#pragma unroll
+            for (int c = 0; c < NX; c++) {
+                float x, yv;
+                if (c == p) {
+                    yv = 0.f - f;
+                    x = 1.0f;
+                } else {
+                    x = th[c];
+                    yv = x - f * prow[c];
+                }
+                const float piv = x * pvInv;
+                th[c] = owner ? piv : yv;
+            }
+        }
+        if (act) {
+            float* Pk1 = bf.Pinv + ((size_t)b * N + k + 1) * BROW;
+            float row[NX];
+#pragma unroll
+            for (int x = 0; x < NX; x++) row[x] = -th[x];
+            gstore_vec<NX>(Pk1 + (size_t)y * BR + NX, row);
         }
     }
 }

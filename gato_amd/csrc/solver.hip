@@ -39,6 +39,7 @@ struct GatoSolver {
     int adapt_rho;
     int fuse_schur;  // Schur complement formed inside the PCG kernel (GATO_SCHUR_FUSED, default 1)
     int fuse_step;   // dz + merit + line search in one launch (GATO_STEP_FUSED, default 1); both are read when the solver is created
+    int schur_rowlane;  // stand-alone Schur kernel with one row per lane (GATO_SCHUR_ROWLANE; default: nq odd)
     uint32_t max_iters_alloc;
     Buffers bf;
     float *d_xu_own, *d_xs_own, *d_ref_own, *d_merit_init0, *d_drho_init, *d_rho_init, *d_scratch_B;
@@ -100,6 +101,7 @@ extern "C" int gato_create(int plant, int N, int B, const GatoParams* params, Ga
     s->adapt_rho = 1;
     s->fuse_schur = getenv("GATO_SCHUR_FUSED") ? atoi(getenv("GATO_SCHUR_FUSED")) : 1;
     s->fuse_step = getenv("GATO_STEP_FUSED") ? atoi(getenv("GATO_STEP_FUSED")) : 1;
+    s->schur_rowlane = getenv("GATO_SCHUR_ROWLANE") ? atoi(getenv("GATO_SCHUR_ROWLANE")) : (s->nq % 2);
     s->profiling = 0;
     s->last_stream = nullptr;
     memset(s->stage_us, 0, sizeof(s->stage_us));
@@ -178,7 +180,10 @@ template<class M> static void launch_schur(GatoSolver* s, hipStream_t st, float 
     // (AGPR moves, a few spills) but still ahead of a lane-per-knot kernel pair: 185 vs 238 us per launch at C3
     const long probs = (long)s->B * s->N;
     constexpr int LPP = (M::NQ % 2 == 0) ? 4 : 2;
-    hipLaunchKernelGGL((schurq_kernel<M, LPP>), dim3(cdiv(probs * LPP, 256), 2), dim3(256), 0, st, s->bf, s->N, s->B, dt);
+    if (s->schur_rowlane)   // one row per lane, 16 lanes per knot: the default for nq odd (GATO_SCHUR_ROWLANE)
+        hipLaunchKernelGGL((schur1_kernel<M>), dim3(cdiv(probs * 16, 256), 2), dim3(256), 0, st, s->bf, s->N, s->B, dt);
+    else
+        hipLaunchKernelGGL((schurq_kernel<M, LPP>), dim3(cdiv(probs * LPP, 256), 2), dim3(256), 0, st, s->bf, s->N, s->B, dt);
     if (force_stair || !pcg_folds_stair<M>(s)) hipLaunchKernelGGL((schur2_kernel<M>), dim3(cdiv(probs, 64)), dim3(64), 0, st, s->bf, s->N, s->B);
 }
 static int g_pcg_variant = -1;  // test / tuning override (GATO_PCG_VARIANT): 0 strided rows, 1 RPT=6, 2 RPT=3, 3 RPT=2
