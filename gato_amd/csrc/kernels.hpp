@@ -1674,7 +1674,9 @@ __global__ __launch_bounds__(MAXT) void pcgc_kernel(Buffers bf, int N, int B, ui
 // dz recovery (computeDzBatchedKernel, schur_linsys.cuh:316-431), one lane per (b,k); q, r are overwritten by the KKT residuals
 // =========================================================================================================================
 // dz of knot k of trajectory b (computeDz, kkt.cuh), also left in `mirror` (the trajectory's step in LDS) when given
-template<class M>
+// PART: 0 = state and control rows of knot k, 1 = state row only, 2 = control row only (two lanes share a knot in the step kernel:
+// each then holds only its half of D and the kernel's register count is the larger half, not the sum)
+template<class M, int PART = 0>
 GATO_DEV void dz_knot(const Buffers& bf, int N, int b, int k, float dt, float* mirror)
 {
     constexpr int NQ = M::NQ, NX = 2 * NQ, NU = NQ, KS = NX + NU;
@@ -1683,15 +1685,15 @@ GATO_DEV void dz_knot(const Buffers& bf, int N, int b, int k, float dt, float* m
     const float* lam = bf.lambda + (size_t)b * (N + 2) * NX;
     float* dz = bf.dz + (size_t)b * traj + (size_t)k * KS;
     const float h2 = half_dt_sq(dt);
-    float lk[NX], lk1[NX], Dm[3 * NQ * NQ];
-    load_vec<NX, NX>(lk, lam + (size_t)(k + 1) * NX);
+    float lk1[NX], Dm[3 * NQ * NQ];  // only the part of D a PART reads is loaded (and allocated)
     const bool inner = k < N - 1;
     // unconditional loads (valid memory for the last knot too: lambda's zero padding block, an unused D slot)
     load_vec<NX, NX>(lk1, lam + (size_t)(k + 2) * NX);
-    load_vec<3 * NQ * NQ, 3 * NQ * NQ>(Dm, bf.D + bk * 3 * NQ * NQ);
-    // state row
-    {
-        float qk[NX], res[NX], Qi[NQ * NQ], di[NQ], out[NX];
+    if constexpr (PART != 2) load_vec<2 * NQ * NQ, 3 * NQ * NQ>(Dm, bf.D + bk * 3 * NQ * NQ);
+    if constexpr (PART != 1) load_vec<NQ * NQ, NQ * NQ>(Dm + 2 * NQ * NQ, bf.D + bk * 3 * NQ * NQ + 2 * NQ * NQ);
+    if constexpr (PART != 2) {  // state row
+        float lk[NX], qk[NX], res[NX], Qi[NQ * NQ], di[NQ], out[NX];
+        load_vec<NX, NX>(lk, lam + (size_t)(k + 1) * NX);
         load_vec<NX, NX>(qk, bf.q + bk * NX);
         load_vec<NQ * NQ, NQ * NQ>(Qi, bf.Qqi + bk * NQ * NQ);
         load_vec<NQ, NQ>(di, bf.Qdi + bk * NQ);
@@ -1729,14 +1731,13 @@ GATO_DEV void dz_knot(const Buffers& bf, int N, int b, int k, float dt, float* m
         }
         store_vec<NX, NX>(bf.q + bk * NX, res);
     }
-    // control row
-    float* rk = bf.r + bk * NU;
-    if (!inner) {
+    if constexpr (PART != 1) {  // control row
+        float* rk = bf.r + bk * NU;
+        if (!inner) {
 #pragma unroll
-        for (int i = 0; i < NU; i++) rk[i] = 0.f;
-        return;
-    }
-    {
+            for (int i = 0; i < NU; i++) rk[i] = 0.f;
+            return;
+        }
         float rr[NU], ri[NU], su[NU], out[NU];
         load_vec<NU, NU>(rr, rk);
         load_vec<NU, NU>(ri, bf.Rdi + bk * NU);
@@ -1835,7 +1836,8 @@ __global__ __launch_bounds__(512) void step_kernel(Buffers bf, Costs cw, int N, 
     float* dzs = lds;
     float* mer = lds + ((traj + 3) & ~3);
     if (b == 0 && t == 0) bf.ctrl->iters_done = sqp_iter + 1;
-    if (t < N) dz_knot<M>(bf, N, b, t, dt, dzs);
+    if (t < N) dz_knot<M, 1>(bf, N, b, t, dt, dzs);              // state rows
+    else if (t < 2 * N) dz_knot<M, 2>(bf, N, b, t - N, dt, dzs);  // control rows
     // The loop breaks before the line search (bsqp.cuh:165); every workgroup takes the same branch.  `done` is raised by the NEXT
     // launch (kkt_kernel): set here it could stop a workgroup of this very launch before its dz.
     if ((float)bf.num_solved[sqp_iter] >= thresh) return;
