@@ -235,7 +235,7 @@ template<class M> static void launch_pcg_fused(GatoSolver* s, hipStream_t st, fl
         // where the workgroup is padded to one wavefront)
         const size_t fold = (size_t)2 * s->N * NX * NX * sizeof(float), park = (size_t)3 * (NX / 4) * T * 4 * sizeof(float);
         const size_t lds = (size_t)(2 * s->vecp + 36) * sizeof(float) + (fold > park ? fold : park);
-        hipLaunchKernelGGL((pcgc_kernel<M, 3, 512, true, true>), dim3(s->B), dim3(T), lds, st, s->bf, s->N, s->B, s->p.max_pcg_iters, sqp_iter, 0, dt);
+        hipLaunchKernelGGL((pcgc_kernel<M, 3, 256, true, true>), dim3(s->B), dim3(T), lds, st, s->bf, s->N, s->B, s->p.max_pcg_iters, sqp_iter, 0, dt);
     }
 }
 
