@@ -37,6 +37,8 @@ struct GatoSolver {
     GatoParams p;
     Costs cw;
     int adapt_rho;
+    float* zero_slab;   // dz | pcg_iters | converged | ctrl | num_solved: zeroed by one memset at the start of a solve
+    size_t zero_words;
     int fuse_schur;  // Schur complement formed inside the PCG kernel (GATO_SCHUR_FUSED, default 1)
     int fuse_step;   // dz + merit + line search in one launch (GATO_STEP_FUSED, default 1); both are read when the solver is created
     int schur_rowlane;  // stand-alone Schur kernel with one row per lane (GATO_SCHUR_ROWLANE; default: nq odd)
@@ -119,12 +121,23 @@ extern "C" int gato_create(int plant, int N, int B, const GatoParams* params, Ga
     DA(bf.q, BN * nx); DA(bf.r, BN * nu); DA(bf.c, BN * nx);
     DA(bf.Qqi, BN * nq * nq); DA(bf.Qdi, BN * nq); DA(bf.Rdi, BN * nu);
     DA(bf.S, BN * s->brow); DA(bf.Pinv, BN * s->brow); DA(bf.gamma, (size_t)B * s->vecp);  // zero padding blocks are relied upon
-    DA(bf.dz, (size_t)B * s->traj);
+    {
+        // everything a solve zeroes first (bsqp.cuh:112-114 + the device-side loop control) lives in ONE slab: one memset per solve
+        auto up = [](size_t n) { return (n + 63) & ~(size_t)63; };  // 256-byte granules, in 4-byte words
+        const size_t o_dz = 0, o_pi = up((size_t)B * s->traj), o_cv = o_pi + up(B), o_ct = o_cv + up(B), o_ns = o_ct + up(sizeof(Ctrl) / 4);
+        s->zero_words = o_ns + up(s->max_iters_alloc);
+        float* slab = nullptr;
+        DA(slab, s->zero_words);
+        s->zero_slab = slab;
+        bf.dz = slab + o_dz;
+        bf.pcg_iters = reinterpret_cast<uint32_t*>(slab + o_pi);
+        bf.converged = reinterpret_cast<int32_t*>(slab + o_cv);
+        bf.ctrl = reinterpret_cast<Ctrl*>(slab + o_ct);
+        bf.num_solved = reinterpret_cast<uint32_t*>(slab + o_ns);
+    }
     DA(bf.merit, (size_t)B * NUM_ALPHAS); DA(bf.merit_cur, B); DA(bf.step, B);
-    DA(bf.converged, B); DA(bf.pcg_iters, B);
     DA(bf.st_pcg_iters, (size_t)s->max_iters_alloc * B); DA(bf.st_min_merit, (size_t)s->max_iters_alloc * B);
     DA(bf.st_step, (size_t)s->max_iters_alloc * B);
-    DA(bf.ctrl, 1); DA(bf.num_solved, s->max_iters_alloc);
     DA(s->d_xu_own, (size_t)B * s->traj); DA(s->d_xs_own, (size_t)B * nx); DA(s->d_ref_own, (size_t)B * 6 * N);
     DA(s->d_merit_init0, B); DA(s->d_drho_init, B); DA(s->d_rho_init, B); DA(s->d_scratch_B, (size_t)B * nx);
 #undef DA
@@ -335,11 +348,7 @@ template<class M> static int solve_impl(GatoSolver* s, float* d_xu, float dt, co
     s->last_stream = st;
     size_t ei = 0;
     // bsqp.cuh:112-114 (+ the device-side loop control)
-    HIPCHK(hipMemsetAsync(bf.dz, 0, (size_t)B * s->traj * sizeof(float), st));
-    HIPCHK(hipMemsetAsync(bf.pcg_iters, 0, B * sizeof(uint32_t), st));
-    HIPCHK(hipMemsetAsync(bf.converged, 0, B * sizeof(int32_t), st));
-    HIPCHK(hipMemsetAsync(bf.ctrl, 0, sizeof(Ctrl), st));
-    HIPCHK(hipMemsetAsync(bf.num_solved, 0, s->max_iters_alloc * sizeof(uint32_t), st));
+    HIPCHK(hipMemsetAsync(s->zero_slab, 0, s->zero_words * sizeof(float), st));  // dz, pcg_iters, converged, ctrl, num_solved
     mark(s, st, -1, ei);
     launch_merit<M>(s, st, 1, dt, 0, -1, bf.merit_cur);  // bsqp.cuh:116-118
     HIPCHK(hipMemcpyAsync(s->d_merit_init0, bf.merit_cur, B * sizeof(float), hipMemcpyDeviceToDevice, st));
@@ -369,8 +378,9 @@ template<class M> static int solve_impl(GatoSolver* s, float* d_xu, float dt, co
             mark(s, st, ST_LS, ei);
         }
     }
-    launch_merit<M>(s, st, 1, dt, 0, -1, bf.merit_cur);  // final merit of the returned xu (bsqp.cuh:180-182)
-    mark(s, st, ST_MERIT, ei);
+    // The merit of the returned xu (bsqp.cuh:180-182) needs no launch: merit_cur already holds it -- the line search stores the merit
+    // of the step it accepts, evaluated at fma(alpha, dz, xu), which is exactly what it then writes to xu
+    // (tests/test_gpu_parity.py::test_final_merit_is_the_merit_of_the_returned_iterates recomputes it).
     HIPCHK(hipMemcpyAsync(bf.drho, s->d_drho_init, B * sizeof(float), hipMemcpyDeviceToDevice, st));  // bsqp.cuh:189; rho is NOT reset
     HIPCHK(hipGetLastError());
     return GATO_OK;

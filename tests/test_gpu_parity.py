@@ -279,6 +279,18 @@ def test_hparam_sweep_settings_parity(plant, N, B, shard):
     assert np.all(np.isfinite(r5["XU"])) and np.all(r5["final_merit"] <= r5["initial_merit"])
 
 
+@pytest.mark.parametrize("plant,N,B", [("indy7", 32, 16), ("iiwa14", 16, 5), ("indy7", 128, 2)])
+def test_final_merit_is_the_merit_of_the_returned_iterates(plant, N, B):
+    """solve() returns merit_cur (the merit the line search stored for the accepted step) without a final merit launch; a fresh merit
+    evaluation of the returned iterates (stage 6) must give the same bits."""
+    nat, orc, pr = make(plant, N, B, 3.0, max_sqp_iters=4)
+    rg = nat.solve(pr["xu"], DT, pr["x_s"], pr["ref"])
+    final = rg["final_merit"].copy()
+    nat.stage("merit1", rg["XU"], DT, pr["x_s"], pr["ref"])
+    np.testing.assert_array_equal(nat.read("merit_cur"), final)
+    assert relscale(orc.merit(rg["XU"], pr["x_s"], pr["ref"], DT, num_alphas=1, zero_dz=True)[:, 0], final) < 1e-4
+
+
 def test_sim_forward_and_ee_pos():
     from oracle import oracle as O
     nat, orc, pr = make("iiwa14", 8, 5, 4.0)
