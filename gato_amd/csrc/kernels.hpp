@@ -1417,6 +1417,7 @@ __global__ __launch_bounds__(MAXT) void pcgc_kernel(Buffers bf, int N, int B, ui
 {
     constexpr int NQ = M::NQ, NX = 2 * NQ, BR = 3 * NX, BROW = 3 * NX * NX;
     constexpr int PARTS = (FUSE || MAXT <= 256) ? 1 : (MAXT <= 512 ? 2 : 4);  // FUSE is only launched with <= 256 threads
+    constexpr int LA2 = (NX % 4 == 0) ? 4 : 2;  // alignment (floats) of an nx-float row in the LDS buffers
     static_assert(NX % RPT == 0, "rows of one thread must share a block row");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     if (bf.ctrl->done) return;
@@ -1493,7 +1494,7 @@ __global__ __launch_bounds__(MAXT) void pcgc_kernel(Buffers bf, int N, int B, ui
             const int i0 = rr - kb * NX;
             if (have) {
 #pragma unroll
-                for (int u = 0; u < RPT; u++) store_vec<NX, 2>(bufA + (kb * NX + i0 + u) * NX, &Srow[u][0]);
+                for (int u = 0; u < RPT; u++) store_vec<NX, LA2>(bufA + (kb * NX + i0 + u) * NX, &Srow[u][0]);
             }
             __syncthreads();
 #pragma unroll
@@ -1519,48 +1520,58 @@ __global__ __launch_bounds__(MAXT) void pcgc_kernel(Buffers bf, int N, int B, ui
             const int i0 = rr - kb * NX;
             if (have) {
 #pragma unroll
-                for (int u = 0; u < RPT; u++) store_vec<NX, 2>(bufA + (kb * NX + i0 + u) * NX, &Prow[u][NX]);
+                for (int u = 0; u < RPT; u++) store_vec<NX, LA2>(bufA + (kb * NX + i0 + u) * NX, &Prow[u][NX]);
             }
             __syncthreads();
+            constexpr int LA = (NX % 4 == 0) ? 4 : 2;  // LDS rows of nx floats: 16-byte aligned when nx % 4 == 0
             if (have && kb >= 1) {
+                // every operand row is read from LDS once and feeds the thread's RPT rows (the sums run over jj in the same order)
                 const float* Pm1 = bufA + (kb - 1) * NX * NX;
+                float scr[RPT][NX];
 #pragma unroll
-                for (int u = 0; u < RPT; u++) {
-                    float scr[NX];
+                for (int u = 0; u < RPT; u++)
 #pragma unroll
-                    for (int x = 0; x < NX; x++) scr[x] = 0.f;
+                    for (int x = 0; x < NX; x++) scr[u][x] = 0.f;
 #pragma unroll
-                    for (int jj = 0; jj < NX; jj++) {
-                        float prow_[NX];
-                        load_vec<NX, 2>(prow_, Pm1 + jj * NX);
+                for (int jj = 0; jj < NX; jj++) {
+                    float prow_[NX];
+                    load_vec<NX, LA>(prow_, Pm1 + jj * NX);
 #pragma unroll
-                        for (int x = 0; x < NX; x++) scr[x] += Srow[u][jj] * prow_[x];
-                    }
-                    store_vec<NX, 2>(bufB + (kb * NX + i0 + u) * NX, scr);
+                    for (int u = 0; u < RPT; u++)
+#pragma unroll
+                        for (int x = 0; x < NX; x++) scr[u][x] += Srow[u][jj] * prow_[x];
                 }
+#pragma unroll
+                for (int u = 0; u < RPT; u++) store_vec<NX, LA>(bufB + (kb * NX + i0 + u) * NX, scr[u]);
             }
             __syncthreads();
             if (have) {
                 const float* sc = bufB + kb * NX * NX;
+                float res[RPT][NX];
 #pragma unroll
-                for (int u = 0; u < RPT; u++) {
-                    float res[NX];
+                for (int u = 0; u < RPT; u++)
 #pragma unroll
-                    for (int x = 0; x < NX; x++) res[x] = 0.f;
-                    if (kb >= 1) {
+                    for (int x = 0; x < NX; x++) res[u][x] = 0.f;
+                if (kb >= 1) {
 #pragma unroll
-                        for (int jj = 0; jj < NX; jj++) {
-                            float srow_[NX];
-                            load_vec<NX, 2>(srow_, sc + jj * NX);
+                    for (int jj = 0; jj < NX; jj++) {
+                        float srow_[NX];
+                        load_vec<NX, LA>(srow_, sc + jj * NX);
 #pragma unroll
-                            for (int x = 0; x < NX; x++) res[x] += Prow[u][NX + jj] * srow_[x];
-                        }
+                        for (int u = 0; u < RPT; u++)
 #pragma unroll
-                        for (int x = 0; x < NX; x++) res[x] = -res[x];
+                            for (int x = 0; x < NX; x++) res[u][x] += Prow[u][NX + jj] * srow_[x];
                     }
 #pragma unroll
-                    for (int x = 0; x < NX; x++) Prow[u][x] = res[x];
-                    store_vec<NX, 2>(bufA + (kb * NX + i0 + u) * NX, res);
+                    for (int u = 0; u < RPT; u++)
+#pragma unroll
+                        for (int x = 0; x < NX; x++) res[u][x] = -res[u][x];
+                }
+#pragma unroll
+                for (int u = 0; u < RPT; u++) {
+#pragma unroll
+                    for (int x = 0; x < NX; x++) Prow[u][x] = res[u][x];
+                    store_vec<NX, LA>(bufA + (kb * NX + i0 + u) * NX, res[u]);
                 }
             }
             __syncthreads();
