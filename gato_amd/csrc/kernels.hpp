@@ -201,39 +201,59 @@ GATO_DEV float merit_term(const Buffers& bf, const Costs& cw, int N, int b, int 
     const float* xu = bf.xu + (size_t)b * traj + (size_t)k * KS;
     const float* dz = dzb + (size_t)k * KS;
     const bool last = (k == N - 1);
-
     // [x_k, u_k, x_{k+1}] + alpha [dz...]; the last knot has x only.  Loads are UNCONDITIONAL (a branch around a load makes hipcc wait for
-    // each one separately: 45 % of this kernel's cycles were such waits): last-knot lanes read the previous knot's tail instead, then zero it.
+    // each one separately): last-knot lanes read the previous knot's tail instead, then zero it.  Order of work = order of register
+    // need: q first (kinematics, then M^-1 with nothing else live), then qd and u (costs, bias forces), x_{k+1} last.
     constexpr int AL = (KS % 2 == 0) ? 2 : 1;  // knot offsets are multiples of KS floats, TRAJ = KS N - NU has the parity of KS for NU | KS
-    float s[KS];  // x_k, u_k at the trial point; x_{k+1} is fetched after the dynamics (12 fewer live registers through M^-1)
     const float* xt = last ? xu - KS : xu;
     const float* dzt = last ? dz - KS : dz;
+    float sq[NQ];
     {
-        load_vec<NX, AL>(s, xu);
+        load_vec<NQ, AL>(sq, xu);
+        if (use_dz) {
+            float t[NQ];
+            load_vec<NQ, AL>(t, dz);
+#pragma unroll
+            for (int i = 0; i < NQ; i++) sq[i] += alpha * t[i];
+        }
+    }
+    RBD<M> d;
+    d.set_q(sq);
+    float cost = 0.f;
+    {
+        // ---- end-effector and joint-limit terms of the cost (plant::trackingcost, indy7_plant.cuh:266-318)
+        const float* ref = bf.ref + (size_t)b * 6 * N + 6 * k;
+        float e[3];
+        d.ee_pos(e);
+        const float w = last ? cw.N_cost : cw.q_cost;
+#pragma unroll
+        for (int i = 0; i < NQ; i++) cost += cw.q_lim_cost * joint_barrier(sq[i], M::Q_LIM[i][0], M::Q_LIM[i][1]);
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            const float err = e[i] - ref[i];
+            cost += (float)(0.5 * (double)w * (double)err * (double)err);
+        }
+    }
+    typename RBD<M>::MinvT Mi;
+    if (opaque_true()) d.minv(Mi);  // its own basic block, entered with q, sin/cos and one accumulator live
+    float s[KS];  // only [NQ, KS) is used: qd_k, u_k at the trial point
+    {
+        load_vec<NQ, 1>(s + NQ, xu + NQ);
         load_vec<NU, AL>(s + NX, xt + NX);
         if (use_dz) {
             float t[KS];
-            load_vec<NX, AL>(t, dz);
+            load_vec<NQ, 1>(t + NQ, dz + NQ);
             load_vec<NU, AL>(t + NX, dzt + NX);
 #pragma unroll
-            for (int i = 0; i < KS; i++) s[i] += alpha * t[i];
+            for (int i = NQ; i < KS; i++) s[i] += alpha * t[i];
         }
 #pragma unroll
         for (int i = NX; i < KS; i++) s[i] = last ? 0.f : s[i];
     }
-    const float* ref = bf.ref + (size_t)b * 6 * N + 6 * k;
-
-    RBD<M> d;
-    d.set_q(s);
-    // ---- cost (plant::trackingcost, indy7_plant.cuh:266-318)
-    float e[3];
-    d.ee_pos(e);
-    float cost = 0.f;
 #pragma unroll
     for (int i = 0; i < NQ; i++) {
         const float err = s[NQ + i];
         float t = 0.5f * cw.qd_cost * err * err;
-        t += cw.q_lim_cost * joint_barrier(s[i], M::Q_LIM[i][0], M::Q_LIM[i][1]);
         if (cw.vel_lim_cost != 0.f) t += cw.vel_lim_cost * joint_barrier(err, M::V_LIM[i][0], M::V_LIM[i][1]);
         cost += t;
     }
@@ -246,19 +266,14 @@ GATO_DEV float merit_term(const Buffers& bf, const Costs& cw, int N, int b, int 
             cost += t;
         }
     }
-    const float w = last ? cw.N_cost : cw.q_cost;
-#pragma unroll
-    for (int i = 0; i < 3; i++) {
-        const float err = e[i] - ref[i];
-        cost += (float)(0.5 * (double)w * (double)err * (double)err);
-    }
     // ---- constraint violation
     float con = 0.f;
     if (!last) {
-        float fe[6], qdd[NQ];
+        float fe[6], qdd[NQ], f[NQ][6];
 #pragma unroll
         for (int i = 0; i < 6; i++) fe[i] = bf.f_ext[6 * b + i];
-        d.forward_dynamics(s + NQ, s + NX, fe, qdd);
+        d.rnea_lean(s + NQ, fe, f);
+        RBD<M>::fd_finish(Mi, s + NX, f, qdd);
         float xn[NX];
         load_vec<NX, AL>(xn, xt + KS);
         if (use_dz) {
@@ -270,7 +285,7 @@ GATO_DEV float merit_term(const Buffers& bf, const Costs& cw, int N, int b, int 
 #pragma unroll
         for (int i = 0; i < NQ; i++) {
             const float qdn = s[NQ + i] + dt * qdd[i];
-            const float qn = (float)((double)(s[i] + dt * s[NQ + i]) + 0.5 * (double)qdd[i] * (double)dt * (double)dt);
+            const float qn = (float)((double)(sq[i] + dt * s[NQ + i]) + 0.5 * (double)qdd[i] * (double)dt * (double)dt);
             con += fabsf(xn[i] - qn);
             con += fabsf(xn[NQ + i] - qdn);
         }
@@ -1703,11 +1718,9 @@ GATO_DEV void dz_knot(const Buffers& bf, int N, int b, int k, float dt, float* m
     if constexpr (PART != 2) load_vec<2 * NQ * NQ, 3 * NQ * NQ>(Dm, bf.D + bk * 3 * NQ * NQ);
     if constexpr (PART != 1) load_vec<NQ * NQ, NQ * NQ>(Dm + 2 * NQ * NQ, bf.D + bk * 3 * NQ * NQ + 2 * NQ * NQ);
     if constexpr (PART != 2) {  // state row
-        float lk[NX], qk[NX], res[NX], Qi[NQ * NQ], di[NQ], out[NX];
+        float lk[NX], qk[NX], res[NX], out[NX];
         load_vec<NX, NX>(lk, lam + (size_t)(k + 1) * NX);
         load_vec<NX, NX>(qk, bf.q + bk * NX);
-        load_vec<NQ * NQ, NQ * NQ>(Qi, bf.Qqi + bk * NQ * NQ);
-        load_vec<NQ, NQ>(di, bf.Qdi + bk * NQ);
 #pragma unroll
         for (int x = 0; x < NX; x++) {
             float s = 0.f;
@@ -1718,6 +1731,11 @@ GATO_DEV void dz_knot(const Buffers& bf, int N, int b, int k, float dt, float* m
             }
             const float scr = s + lk[x];
             res[x] = qk[x] - scr;
+        }
+        float Qi[NQ * NQ], di[NQ];
+        if (opaque_true()) {  // fetched only now: D's 2 nq^2 registers are free again
+            load_vec<NQ * NQ, NQ * NQ>(Qi, bf.Qqi + bk * NQ * NQ);
+            load_vec<NQ, NQ>(di, bf.Qdi + bk * NQ);
         }
 #pragma unroll
         for (int y = 0; y < NX; y++) {

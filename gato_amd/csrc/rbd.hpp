@@ -209,6 +209,46 @@ struct RBD {
             rnea_bwd<K - 1>(f);
         }
     }
+    // Bias forces only (f accumulated over the subtrees, c[k] = f[k][2]) at zero accelerations: v_k, a_k live for ONE body -- each
+    // body's force is formed as soon as its velocity and acceleration exist (same operations and order per value as rnea()), so the
+    // forward-dynamics-only paths (merit, sim) carry 36 + 12 floats through the recursion instead of 108.
+    template<int K> GATO_DEV void rnea_lean_fwd(const float* qd, const float* vp, const float* ap, float (*f)[6], const float* fext) const
+    {
+        float v[6], a[6];
+        if constexpr (K == 0) {
+            const float g6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, G};
+#pragma unroll
+            for (int r = 0; r < 6; r++) v[r] = 0.f;
+            v[2] = qd[0];
+            X<0>(g6, a);
+        } else {
+            X<K>(vp, v);
+            X<K>(ap, a);
+            v[2] += qd[K];
+            a[0] += v[1] * qd[K];
+            a[1] -= v[0] * qd[K];
+            a[3] += v[4] * qd[K];
+            a[4] -= v[3] * qd[K];
+        }
+        {
+            float Iv[6], t[6];
+            Imul<K>(a, f[K]);
+            Imul<K>(v, Iv);
+            fxv(v, Iv, t);
+#pragma unroll
+            for (int r = 0; r < 6; r++) f[K][r] += t[r];
+            if constexpr (K == NQ - 1) {
+#pragma unroll
+                for (int r = 0; r < 6; r++) f[K][r] -= fext[r];
+            }
+        }
+        if constexpr (K + 1 < NQ) rnea_lean_fwd<K + 1>(qd, v, a, f, fext);
+    }
+    GATO_DEV void rnea_lean(const float* qd, const float* fext, float (*f)[6]) const
+    {
+        rnea_lean_fwd<0>(qd, nullptr, nullptr, f, fext);
+        rnea_bwd<NQ - 1>(f);
+    }
     GATO_DEV void rnea(const float* qd, const float* qdd, const float* fext, float (*v)[6], float (*a)[6], float (*f)[6]) const
     {
         rnea_fwd<0>(qd, qdd, v, a);
@@ -332,9 +372,9 @@ struct RBD {
     GATO_DEV void forward_dynamics(const float* qd, const float* u, const float* fext, float* qdd) const
     {
         MinvT Mi;
-        minv(Mi);
-        float v[NQ][6], a[NQ][6], f[NQ][6];
-        rnea(qd, nullptr, fext, v, a, f);
+        if (opaque_true()) minv(Mi);  // its own basic block: M^-1's 110 live values are gone before the recursion below starts
+        float f[NQ][6];
+        rnea_lean(qd, fext, f);
         fd_finish(Mi, u, f, qdd);
     }
 
