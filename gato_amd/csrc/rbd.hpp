@@ -517,7 +517,7 @@ struct RBD {
         if (opaque_true()) minv(Mi);
         float v[NQ][6], a[NQ][6], f[NQ][6], qdd[NQ];
         if (opaque_true()) {
-            rnea(qd, nullptr, fext, v, a, f);
+            rnea_lean(qd, fext, f);  // bias forces only: one body of v, a live
             fd_finish(Mi, u, f, qdd);
             after_qdd(qdd);
         }
