@@ -458,16 +458,9 @@ struct RBD {
             grad_bwd<J, I2 - 1, QD>(f, df, dc);
         }
     }
-    // dc_dq[J][i] = d c_i / d q_J, dc_dqd[J][i] = d c_i / d qd_J   (v,a,f from rnea() at the solved qdd)
-    template<int J> GATO_DEV void rnea_grad_cols(const float* qd, const float (*v)[6], const float (*a)[6], const float (*f)[6],
-                                                 const float (*Iv)[6], float (*dc_dq)[NQ], float (*dc_dqd)[NQ]) const
-    {
-        rnea_grad_col<J>(qd, v, a, f, Iv, dc_dq[J], dc_dqd[J]);
-        if constexpr (J + 1 < NQ) rnea_grad_cols<J + 1>(qd, v, a, f, Iv, dc_dq, dc_dqd);
-    }
-    // one derivative column only (the column-split KKT kernel: a wavefront works on ONE J for 64 knots)
-    template<int J> GATO_DEV void rnea_grad_col(const float* qd, const float (*v)[6], const float (*a)[6], const float (*f)[6],
-                                                const float (*Iv)[6], float* dcq, float* dcd) const
+    // dcq[i] = d c_i / d q_J, dcd[i] = d c_i / d qd_J (v, a, f from rnea() at the solved qdd): one derivative column
+    template<int J> GATO_DEV void rnea_grad_col(const float* qd, const float (*v)[6], const float (*a)[6], const float (*f)[6], float* dcq,
+                                                float* dcd) const
     {
         // Each pass in its own basic block (a branch the compiler cannot fold): instruction selection and scheduling work per block,
         // so the two independent passes are not interleaved for ILP (which kept 440 registers live instead of 270).
@@ -490,7 +483,7 @@ struct RBD {
                                                        const MinvT& Mi, E&& emit) const
     {
         float dcq[NQ], dcd[NQ];
-        rnea_grad_col<J>(qd, v, a, f, nullptr, dcq, dcd);
+        rnea_grad_col<J>(qd, v, a, f, dcq, dcd);
         if (opaque_true()) {
             float colq[NQ], cold[NQ], colm[NQ];
 #pragma unroll
@@ -525,40 +518,6 @@ struct RBD {
         grad_column<JA>(qd, v, a, f, Mi, emit);
         if constexpr (JB != JA) grad_column<JB>(qd, v, a, f, Mi, emit);
     }
-    template<int K> GATO_DEV void all_Iv(const float (*v)[6], float (*Iv)[6]) const
-    {
-        Imul<K>(v[K], Iv[K]);
-        if constexpr (K + 1 < NQ) all_Iv<K + 1>(v, Iv);
-    }
-
-    // plant::forwardDynamicsAndGradient(..., d_f_ext) (indy7_plant.cuh:220-259):
-    //   qdd, dqdd_dq[J][i] = d qdd_i / d q_J, dqdd_dqd[J][i], Mi (for d qdd / d u = M^-1)
-    GATO_DEV void forward_dynamics_grad(const float* qd, const float* u, const float* fext, float* qdd, float (*dqdd_dq)[NQ],
-                                        float (*dqdd_dqd)[NQ], MinvT& Mi) const
-    {
-        float v[NQ][6], a[NQ][6], f[NQ][6], Iv[NQ][6];
-        minv(Mi);
-        rnea(qd, nullptr, fext, v, a, f);
-        fd_finish(Mi, u, f, qdd);
-        rnea(qd, qdd, fext, v, a, f);
-        all_Iv<0>(v, Iv);
-        float dcq[NQ][NQ], dcd[NQ][NQ];
-        rnea_grad_cols<0>(qd, v, a, f, Iv, dcq, dcd);
-#pragma unroll
-        for (int J = 0; J < NQ; J++)
-#pragma unroll
-            for (int r = 0; r < NQ; r++) {
-                float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-                for (int c = 0; c < NQ; c++) {
-                    s1 += Mi.sym(r, c) * dcq[J][c];
-                    s2 += Mi.sym(r, c) * dcd[J][c];
-                }
-                dqdd_dq[J][r] = -s1;
-                dqdd_dqd[J][r] = -s2;
-            }
-    }
-
     // ---- forward kinematics: e = origin of the last joint frame, Jc[j] = d e / d q_j ------------------------------
     // p_{n-1} = r_{n-1}; p_i = r_i + R_i p_{i+1},  R_i = E_i^T      (chain of Xhom products, indy7_grid.cuh:1834-1901)
     template<int K> GATO_DEV void fk_chain(float* p) const
