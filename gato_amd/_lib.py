@@ -16,7 +16,7 @@ SYMBOLS = [
     "gato_get_ls_min_merit", "gato_get_ls_step_size", "gato_set_f_ext_batch", "gato_set_rho_penalty_batch", "gato_set_drho_batch",
     "gato_set_mu_batch", "gato_set_pcg_tol_batch", "gato_reset_dual", "gato_reset_rho", "gato_set_rho_adaptation", "gato_sim_forward",
     "gato_ee_pos", "gato_debug_read", "gato_debug_write", "gato_debug_stage", "gato_set_profiling", "gato_get_stage_times_us",
-    "gato_last_error", "gato_version", "gato_reset_async", "gato_copy_final_merit_device",
+    "gato_last_error", "gato_version", "gato_reset_async", "gato_copy_final_merit_device", "gato_set_cost_weights_batch",
 ]
 
 
@@ -61,7 +61,7 @@ def load():
     for n in ("gato_get_sqp_iters", "gato_get_kkt_converged", "gato_get_pcg_iters"):
         getattr(L, n).argtypes = [vp, ip]
     for n in ("gato_get_final_merit", "gato_get_initial_merit", "gato_get_ls_min_merit", "gato_get_ls_step_size", "gato_set_f_ext_batch",
-              "gato_set_mu_batch", "gato_set_pcg_tol_batch"):
+              "gato_set_mu_batch", "gato_set_pcg_tol_batch", "gato_set_cost_weights_batch"):
         getattr(L, n).argtypes = [vp, fp]
     for n in ("gato_set_rho_penalty_batch", "gato_set_drho_batch"):
         getattr(L, n).argtypes = [vp, fp, C.c_int]
@@ -202,6 +202,10 @@ class NativeSolver:
 
     def set_mu_batch(self, v):
         _chk(load().gato_set_mu_batch(self.h, _p(_f32(v, (self.B,)))))
+
+    def set_cost_weights_batch(self, w):
+        """w[B,7] = q, qd, u, N, q_lim, vel_lim, ctrl_lim cost weights per trajectory (extension: SURVEY 8(f)3)"""
+        _chk(load().gato_set_cost_weights_batch(self.h, _p(_f32(w, (self.B, 7)))))
 
     def set_pcg_tol_batch(self, v):
         _chk(load().gato_set_pcg_tol_batch(self.h, _p(_f32(v, (self.B,)))))

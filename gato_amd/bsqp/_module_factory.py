@@ -53,6 +53,10 @@ def make_class(plant, knot_points, batch_size):
         def set_mu_batch(self, mu_batch):
             self._s.set_mu_batch(mu_batch)
 
+        def set_cost_weights_batch(self, w):
+            """extension: w[B,7] = q, qd, u, N, q_lim, vel_lim, ctrl_lim cost weights per trajectory"""
+            self._s.set_cost_weights_batch(w)
+
         def set_pcg_tol_batch(self, pcg_tol_batch):
             self._s.set_pcg_tol_batch(pcg_tol_batch)
 

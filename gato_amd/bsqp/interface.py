@@ -50,6 +50,11 @@ class BSQP:
         if pcg_tol_batch is not None:
             self.solver.set_pcg_tol_batch(np.asarray(pcg_tol_batch, dtype=np.float32).reshape(self.batch_size))
 
+    def set_cost_weights_B(self, weights_B):
+        """Extension (not in the reference facade): weights_B[B,7] = q_cost, qd_cost, u_cost, N_cost, q_lim_cost, vel_lim_cost,
+        ctrl_lim_cost per trajectory, so that a hyper-parameter sweep is one batch."""
+        self.solver.set_cost_weights_batch(np.asarray(weights_B, dtype=np.float32).reshape(self.batch_size, 7))
+
     def solve(self, xcur_B, eepos_goals_B, XU_B=None):
         xcur_B = np.asarray(xcur_B, dtype=np.float32)
         eepos_goals_B = np.asarray(eepos_goals_B, dtype=np.float32)

@@ -27,6 +27,9 @@ constexpr float RHO_FACTOR = 1.2f;   // settings.h:20
 constexpr float RHO_MIN = 1e-8f;     // settings.h:21
 constexpr float RHO_MAX = 10.0f;     // settings.h:22
 
+// Cost weights of ONE trajectory.  The reference has one scalar set per solver (bsqp.cuh:344-350); here they live per trajectory
+// (Buffers::costw, [B][8] floats, filled from the solver's scalars unless gato_set_cost_weights_batch overrides them) so that a
+// hyper-parameter sweep is one batch.
 struct Costs {
     float q_cost, qd_cost, u_cost, N_cost, q_lim_cost, vel_lim_cost, ctrl_lim_cost;
 };
@@ -44,6 +47,7 @@ struct Buffers {
     float* xu; const float* x_s; const float* ref;
     // persistent per-trajectory state
     float *lambda, *rho, *drho, *mu, *pcg_tol, *f_ext;
+    const float* costw;  // [B][8]: q, qd, u, N, q_lim, vel_lim, ctrl_lim cost weights, one padding float
     // KKT (compact) + Schur
     float *D, *Qq, *Qd, *Rd, *q, *r, *c, *Qqi, *Qdi, *Rdi, *S, *Pinv, *gamma, *dz;
     float *merit, *merit_cur, *step;
@@ -53,6 +57,13 @@ struct Buffers {
     Ctrl* ctrl;
     uint32_t* num_solved;  // [max_iters]: trajectories counted as solved after outer iteration i (bsqp.cuh:142-163)
 };
+
+#define GATO_DEV_EARLY __device__ __forceinline__
+GATO_DEV_EARLY Costs load_costs(const Buffers& bf, int b)
+{
+    const float4 lo = reinterpret_cast<const float4*>(bf.costw)[2 * b], hi = reinterpret_cast<const float4*>(bf.costw)[2 * b + 1];
+    return Costs{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z};
+}
 
 // ---- integrator pieces (integrator.cuh:34-37, 143-184), INTEGRATOR_TYPE 2 ----------------------------------------------
 GATO_DEV float half_dt_sq(float dt) { return (float)(0.5 * (double)dt * (double)dt); }
@@ -194,9 +205,10 @@ GATO_DEV float seg_sum(float v, int seg, float* lds_part)
 // =========================================================================================================================
 // one lane's term of the merit function: knot k of trajectory b at xu + alpha dz (dzb: the trajectory's step, global or LDS)
 template<class M>
-GATO_DEV float merit_term(const Buffers& bf, const Costs& cw, int N, int b, int k, float alpha, int use_dz, const float* dzb, float dt)
+GATO_DEV float merit_term(const Buffers& bf, int N, int b, int k, float alpha, int use_dz, const float* dzb, float dt)
 {
     constexpr int NQ = M::NQ, NX = 2 * NQ, NU = NQ, KS = NX + NU;
+    const Costs cw = load_costs(bf, b);
     const int traj = KS * N - NU;
     const float* xu = bf.xu + (size_t)b * traj + (size_t)k * KS;
     const float* dz = dzb + (size_t)k * KS;
@@ -303,7 +315,7 @@ GATO_DEV float merit_term(const Buffers& bf, const Costs& cw, int N, int b, int 
 }
 
 template<class M, int NA>
-__global__ __launch_bounds__(256) void merit_kernel(Buffers bf, Costs cw, int N, int B, float dt, int use_dz, int sqp_iter, float thresh,
+__global__ __launch_bounds__(256) void merit_kernel(Buffers bf, int N, int B, float dt, int use_dz, int sqp_iter, float thresh,
                                                     float* __restrict__ out)
 {
     constexpr int NQ = M::NQ, NX = 2 * NQ, NU = NQ, KS = NX + NU;
@@ -318,7 +330,7 @@ __global__ __launch_bounds__(256) void merit_kernel(Buffers bf, Costs cw, int N,
     const bool live = b < B;
     if (!live) b = B - 1;
     const float alpha = (float)(1.0 / (double)(1 << ai));
-    float m = merit_term<M>(bf, cw, N, b, k, alpha, use_dz, bf.dz + (size_t)b * (KS * N - NU), dt);
+    float m = merit_term<M>(bf, N, b, k, alpha, use_dz, bf.dz + (size_t)b * (KS * N - NU), dt);
     m = seg_sum(m, N, part);
     if (live && k == 0) out[b * NA + ai] = m;
 }
@@ -525,7 +537,7 @@ template<class M, int g> GATO_DEV void kkt_dispatch(int task, const Buffers& bf,
 }
 
 template<class M>
-__global__ __launch_bounds__(64, 2) void kkt_kernel(Buffers bf, Costs cw, int N, int B, float dt, int sqp_iter, float thresh, int row0)
+__global__ __launch_bounds__(64, 2) void kkt_kernel(Buffers bf, int N, int B, float dt, int sqp_iter, float thresh, int row0)
 {
     constexpr int NQ = M::NQ, NX = 2 * NQ, NU = NQ, KS = NX + NU, NT = (NQ + 1) / 2 + 1;
     if (bf.ctrl->done) return;
@@ -553,7 +565,7 @@ __global__ __launch_bounds__(64, 2) void kkt_kernel(Buffers bf, Costs cw, int N,
 #pragma unroll
     for (int i = 0; i < KS + NX; i++) x[i] = xu[i];
     constexpr int BROW = 3 * NX * NX;
-    kkt_costs<M>(bf, cw, x, bf.ref + (size_t)b * 6 * N + 6 * k, bk, bf.rho[b], last, row0 && k == 0, bf.x_s + (size_t)b * NX,
+    kkt_costs<M>(bf, load_costs(bf, b), x, bf.ref + (size_t)b * 6 * N + 6 * k, bk, bf.rho[b], last, row0 && k == 0, bf.x_s + (size_t)b * NX,
                  bf.S + (size_t)b * N * BROW, bf.Pinv + (size_t)b * N * BROW, bf.gamma + (size_t)b * (N + 2) * NX);
     if (last) {
         float c0[NX];
@@ -1855,7 +1867,7 @@ __global__ __launch_bounds__(128) void line_search_kernel(Buffers bf, int traj, 
 // leaves the CU between the three (LDS), two launches and their cache write-back / invalidate are gone.  Lane t < N forms dz_t, then
 // lane t is (alpha index t / N, knot t % N) of the merit evaluation, then all lanes apply the chosen step.
 template<class M>
-__global__ __launch_bounds__(512) void step_kernel(Buffers bf, Costs cw, int N, int B, float dt, int sqp_iter, float thresh, int adapt_rho)
+__global__ __launch_bounds__(512) void step_kernel(Buffers bf, int N, int B, float dt, int sqp_iter, float thresh, int adapt_rho)
 {
     constexpr int NQ = M::NQ, NX = 2 * NQ, NU = NQ, KS = NX + NU;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1874,7 +1886,7 @@ __global__ __launch_bounds__(512) void step_kernel(Buffers bf, Costs cw, int N, 
     {
         const int k = t % N, ai = t / N;
         const float alpha = (float)(1.0 / (double)(1 << ai));
-        float m = merit_term<M>(bf, cw, N, b, k, alpha, 1, dzs, dt);
+        float m = merit_term<M>(bf, N, b, k, alpha, 1, dzs, dt);
         m = seg_sum(m, N, nullptr);  // N <= 64: inside one wavefront
         if (k == 0) {
             mer[ai] = m;

@@ -35,7 +35,8 @@ struct GatoSolver {
     int plant, N, B, nq, nx, nu, traj, vecp, brow;
     int device;
     GatoParams p;
-    Costs cw;
+    Costs cw;          // the solver's scalar cost weights (defaults of every trajectory)
+    float* d_costw;    // [B][8] per-trajectory weights the kernels read
     int adapt_rho;
     float* zero_slab;   // dz | pcg_iters | converged | ctrl | num_solved: zeroed by one memset at the start of a solve
     size_t zero_words;
@@ -117,6 +118,7 @@ extern "C" int gato_create(int plant, int N, int B, const GatoParams* params, Ga
 #define DA(ptr, n) if ((rc = dalloc(s, &(ptr), (n))) != GATO_OK) { gato_destroy(s); return rc; }
     DA(bf.lambda, (size_t)B * s->vecp);
     DA(bf.rho, B); DA(bf.drho, B); DA(bf.mu, B); DA(bf.pcg_tol, B); DA(bf.f_ext, 6 * (size_t)B);
+    { float* cwp = nullptr; DA(cwp, 8 * (size_t)B); s->d_costw = cwp; bf.costw = cwp; }
     DA(bf.D, BN * 3 * nq * nq); DA(bf.Qq, BN * nq * nq); DA(bf.Qd, BN * nq); DA(bf.Rd, BN * nu);
     DA(bf.q, BN * nx); DA(bf.r, BN * nu); DA(bf.c, BN * nx);
     DA(bf.Qqi, BN * nq * nq); DA(bf.Qdi, BN * nq); DA(bf.Rdi, BN * nu);
@@ -151,6 +153,15 @@ extern "C" int gato_create(int plant, int N, int B, const GatoParams* params, Ga
     HIPCHK(hipMemcpy(s->d_rho_init, s->h_rho_init.data(), B * sizeof(float), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(bf.mu, mu.data(), B * sizeof(float), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(bf.pcg_tol, tol.data(), B * sizeof(float), hipMemcpyHostToDevice));
+    {
+        std::vector<float> w(8 * (size_t)B, 0.f);
+        for (int b = 0; b < B; b++) {
+            float* r = &w[8 * (size_t)b];
+            r[0] = s->cw.q_cost; r[1] = s->cw.qd_cost; r[2] = s->cw.u_cost; r[3] = s->cw.N_cost; r[4] = s->cw.q_lim_cost;
+            r[5] = s->cw.vel_lim_cost; r[6] = s->cw.ctrl_lim_cost;
+        }
+        HIPCHK(hipMemcpy(s->d_costw, w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
     HIPCHK(hipDeviceSynchronize());
     *out = s;
     return GATO_OK;
@@ -173,9 +184,9 @@ template<class M> static void launch_merit(GatoSolver* s, hipStream_t st, int na
     const float thresh = (float)s->B * s->p.solve_ratio;
     const long n = (long)s->B * na * s->N;
     if (na == 1)
-        hipLaunchKernelGGL((merit_kernel<M, 1>), dim3(cdiv(n, 256)), dim3(256), 0, st, s->bf, s->cw, s->N, s->B, dt, use_dz, sqp_iter, thresh, out);
+        hipLaunchKernelGGL((merit_kernel<M, 1>), dim3(cdiv(n, 256)), dim3(256), 0, st, s->bf, s->N, s->B, dt, use_dz, sqp_iter, thresh, out);
     else
-        hipLaunchKernelGGL((merit_kernel<M, NUM_ALPHAS>), dim3(cdiv(n, 256)), dim3(256), 0, st, s->bf, s->cw, s->N, s->B, dt, use_dz, sqp_iter,
+        hipLaunchKernelGGL((merit_kernel<M, NUM_ALPHAS>), dim3(cdiv(n, 256)), dim3(256), 0, st, s->bf, s->N, s->B, dt, use_dz, sqp_iter,
                            thresh, out);
 }
 template<class M> static void launch_kkt(GatoSolver* s, hipStream_t st, float dt, int sqp_iter, int row0 = 0)
@@ -183,7 +194,7 @@ template<class M> static void launch_kkt(GatoSolver* s, hipStream_t st, float dt
     // The same task split for EVERY batch size: it changes the generated code (and with it the last bit of D), so choosing it by
     // batch size would make a trajectory's iterates depend on how many neighbours it has.
     constexpr int NT = (M::NQ + 1) / 2 + 1;
-    hipLaunchKernelGGL((kkt_kernel<M>), dim3(cdiv((long)s->B * s->N, 64), NT), dim3(64), 0, st, s->bf, s->cw, s->N, s->B, dt, sqp_iter,
+    hipLaunchKernelGGL((kkt_kernel<M>), dim3(cdiv((long)s->B * s->N, 64), NT), dim3(64), 0, st, s->bf, s->N, s->B, dt, sqp_iter,
                        s->p.solve_ratio * (float)s->B, row0);
 }
 template<class M> static bool pcg_folds_stair(const GatoSolver* s);
@@ -317,7 +328,7 @@ template<class M> static void launch_step(GatoSolver* s, hipStream_t st, float d
 {
     const float thresh = (float)s->B * s->p.solve_ratio;
     const size_t lds = (size_t)(((s->traj + 3) & ~3) + 16) * sizeof(float);
-    hipLaunchKernelGGL((step_kernel<M>), dim3(s->B), dim3(NUM_ALPHAS * s->N), lds, st, s->bf, s->cw, s->N, s->B, dt, sqp_iter, thresh,
+    hipLaunchKernelGGL((step_kernel<M>), dim3(s->B), dim3(NUM_ALPHAS * s->N), lds, st, s->bf, s->N, s->B, dt, sqp_iter, thresh,
                        s->adapt_rho);
 }
 static void launch_ls(GatoSolver* s, hipStream_t st, int sqp_iter)
@@ -533,6 +544,17 @@ extern "C" int gato_set_mu_batch(GatoSolver* s, const float* v)
 {
     if (!s || !v) return fail(GATO_ERR_INVALID, "null argument");
     HIPCHK(hipMemcpy(s->bf.mu, v, s->B * sizeof(float), hipMemcpyHostToDevice));
+    return GATO_OK;
+}
+extern "C" int gato_set_cost_weights_batch(GatoSolver* s, const float* w)
+{
+    if (!s || !w) return fail(GATO_ERR_INVALID, "null argument");
+    int rc = sync_last(s);
+    if (rc) return rc;
+    std::vector<float> p(8 * (size_t)s->B, 0.f);
+    for (int b = 0; b < s->B; b++)
+        for (int i = 0; i < 7; i++) p[8 * (size_t)b + i] = w[7 * (size_t)b + i];
+    HIPCHK(hipMemcpy(s->d_costw, p.data(), p.size() * sizeof(float), hipMemcpyHostToDevice));
     return GATO_OK;
 }
 extern "C" int gato_set_pcg_tol_batch(GatoSolver* s, const float* v)

@@ -80,6 +80,8 @@ class BSQP {
     void set_drho_batch(const T* h, bool set_as_reset_default = true) { chk(gato_set_drho_batch(s_, h, set_as_reset_default)); }
     void set_mu_batch(const T* h) { chk(gato_set_mu_batch(s_, h)); }
     void set_pcg_tol_batch(const T* h) { chk(gato_set_pcg_tol_batch(s_, h)); }
+    // extension: per-trajectory cost weights, h[BatchSize][7] = q, qd, u, N, q_lim, vel_lim, ctrl_lim
+    void set_cost_weights_batch(const T* h) { chk(gato_set_cost_weights_batch(s_, h)); }
     void reset_dual() { chk(gato_reset_dual(s_)); }
     void reset_rho() { chk(gato_reset_rho(s_)); }
     void set_rho_adaptation(bool enabled) { chk(gato_set_rho_adaptation(s_, enabled)); }

@@ -92,6 +92,10 @@ int gato_set_rho_penalty_batch(GatoSolver* s, const float* rho, int set_as_reset
 int gato_set_drho_batch(GatoSolver* s, const float* drho, int set_as_reset_default);
 int gato_set_mu_batch(GatoSolver* s, const float* mu);
 int gato_set_pcg_tol_batch(GatoSolver* s, const float* pcg_tol);
+/* EXTENSION beyond the reference API ("per-trajectory cost weights"): w[B][7] = q_cost, qd_cost, u_cost, N_cost,
+ * q_lim_cost, vel_lim_cost, ctrl_lim_cost of each trajectory; generalises the scalar weights of the constructor (bsqp.cuh:344-350),
+ * which every trajectory has until this is called.  A hyper-parameter sweep (gato_hparam_batch.ipynb) then is ONE batch. */
+int gato_set_cost_weights_batch(GatoSolver* s, const float* w);
 int gato_reset_dual(GatoSolver* s);
 int gato_reset_rho(GatoSolver* s);
 int gato_set_rho_adaptation(GatoSolver* s, int enabled);

@@ -48,6 +48,9 @@ typedef struct {
     int adapt_rho;
     /* persistent per-trajectory state (gato/bsqp/bsqp.cuh:299-327) */
     float *lambda, *rho, *drho, *rho_init, *drho_init, *mu, *pcg_tol, *f_ext;
+    /* cost weights per trajectory, [B][7] = q, qd, u, N, q_lim, vel_lim, ctrl_lim (the reference has one scalar set per solver,
+     * bsqp.cuh:344-350; SURVEY.md 8(f)3 generalises it so that a hyper-parameter sweep is one batch) */
+    float* costw;
     /* KKT + Schur buffers (gato/types.cuh:63-81) */
     float *Q, *R, *q, *r, *A, *Bm, *c, *Qinv, *Rinv, *S, *Pinv, *gamma, *dz;
     float *merit, *merit_cur, *merit_init0, *step;
@@ -404,10 +407,11 @@ static float joint_barrier_hess(float q, float lo, float hi) /* iiwa14_plant.cuh
 }
 
 /* plant::trackingcost (indy7_plant.cuh:266-318): xu = [q, qd, (u)], has_u = (knot < N-1), terminal selects N_cost */
-static float tracking_cost(const Orc* o, const float* xu, const float* ref, int has_u, int terminal)
+typedef struct { float q_cost, qd_cost, u_cost, N_cost, q_lim_cost, vel_lim_cost, ctrl_lim_cost; } OrcCosts;
+
+static float tracking_cost(const Orc* o, const OrcCosts* p, const float* xu, const float* ref, int has_u, int terminal)
 {
     const OrcModel* m = o->model;
-    const OrcParams* p = &o->p;
     int nq = o->nq;
     float e[3], cost = 0.f, terms[3 * NQMAX + 3];
     int n = 0;
@@ -436,10 +440,9 @@ static float tracking_cost(const Orc* o, const float* xu, const float* ref, int 
 
 /* plant::trackingCostGradientAndHessian<computeR> (indy7_plant.cuh:325-421, iiwa14_plant.cuh:339-424).  Q col-major nx x nx.
  * The `blockIdx.x == KNOT_POINTS-1` selector of the reference is never true where this runs: weight = q_cost. */
-static void tracking_cost_grad_hess(const Orc* o, const float* xu, const float* ref, float* Q, float* qv, float* R, float* rv)
+static void tracking_cost_grad_hess(const Orc* o, const OrcCosts* p, const float* xu, const float* ref, float* Q, float* qv, float* R, float* rv)
 {
     const OrcModel* m = o->model;
-    const OrcParams* p = &o->p;
     int nq = o->nq, nx = o->nx;
     int mode = m->barrier_mode;
     float e[3], J[3 * NQMAX], g[NQMAX];
@@ -559,10 +562,10 @@ static void setup_kkt_one(Orc* o, int b, const float* xu, const float* x_s, cons
         integrate(nq, xnew, xk, xk + nq, qdd, dt);
         for (int i = 0; i < nx; i++) c[(k + 1) * nx + i] = xn[i] - xnew[i]; /* integrator_error_inner, integrator.cuh:48-62 */
         integrator_gradient(nq, A + k * nx * nx, Bm + k * nx * nu, dqdd, dt);
-        tracking_cost_grad_hess(o, xk, refb + 6 * k, Q + k * nx * nx, qv + k * nx, R + k * nu * nu, rv + k * nu);
+        tracking_cost_grad_hess(o, (const OrcCosts*)(o->costw + 7 * (size_t)b), xk, refb + 6 * k, Q + k * nx * nx, qv + k * nx, R + k * nu * nu, rv + k * nu);
         if (k == N - 2) {
             /* _lastblock: terminal blocks at x_{N-2} against ref_{N-1} (indy7_plant.cuh:423-447) */
-            tracking_cost_grad_hess(o, xk, refb + 6 * (k + 1), Q + (k + 1) * nx * nx, qv + (k + 1) * nx, NULL, NULL);
+            tracking_cost_grad_hess(o, (const OrcCosts*)(o->costw + 7 * (size_t)b), xk, refb + 6 * (k + 1), Q + (k + 1) * nx * nx, qv + (k + 1) * nx, NULL, NULL);
             for (int i = 0; i < nx; i++) c[i] = xub[i] - x_s[b * nx + i]; /* setup_kkt.cuh:92-95 */
         }
     }
@@ -847,7 +850,7 @@ static void merit_one(Orc* o, int b, int na, float* merit, const float* xu, cons
             float s[3 * NXMAX];
             int cnt = (k == N - 1) ? nx : (2 * nx + nu);
             for (int i = 0; i < cnt; i++) s[i] = xub[k * (nx + nu) + i] + alpha * (zero_dz ? 0.f : dzb[k * (nx + nu) + i]);
-            float cost = tracking_cost(o, s, ref + (size_t)b * 6 * N + 6 * k, k < N - 1, k == N - 1);
+            float cost = tracking_cost(o, (const OrcCosts*)(o->costw + 7 * (size_t)b), s, ref + (size_t)b * 6 * N + 6 * k, k < N - 1, k == N - 1);
             float con = 0.f;
             if (k < N - 1) { /* compute_integrator_error, integrator.cuh:211-233 */
                 float qdd[NQMAX], xn[NXMAX];
@@ -915,11 +918,14 @@ Orc* orc_create(int plant, int N, int B, const OrcParams* p)
     o->lambda = ALLOCF((size_t)B * o->vecp);
     o->rho = ALLOCF(B); o->drho = ALLOCF(B); o->rho_init = ALLOCF(B); o->drho_init = ALLOCF(B);
     o->mu = ALLOCF(B); o->pcg_tol = ALLOCF(B); o->f_ext = ALLOCF(6 * (size_t)B);
+    o->costw = ALLOCF(7 * (size_t)B);
     for (int b = 0; b < B; b++) { /* bsqp.cuh:48-57 */
         o->drho[b] = o->drho_init[b] = 1.0f;
         o->rho[b] = o->rho_init[b] = p->rho;
         o->mu[b] = p->mu;
         o->pcg_tol[b] = p->pcg_tol;
+        float* w = o->costw + 7 * (size_t)b;
+        w[0] = p->q_cost; w[1] = p->qd_cost; w[2] = p->u_cost; w[3] = p->N_cost; w[4] = p->q_lim_cost; w[5] = p->vel_lim_cost; w[6] = p->ctrl_lim_cost;
     }
     o->Q = ALLOCF(BN * nx * nx); o->R = ALLOCF(BN * nu * nu); o->q = ALLOCF(BN * nx); o->r = ALLOCF(BN * nu);
     o->A = ALLOCF(BN * nx * nx); o->Bm = ALLOCF(BN * nx * nu); o->c = ALLOCF(BN * nx);
@@ -942,7 +948,7 @@ void orc_destroy(Orc* o)
 {
     if (!o) return;
     float* fl[] = {o->lambda, o->rho, o->drho, o->rho_init, o->drho_init, o->mu, o->pcg_tol, o->f_ext, o->Q, o->R, o->q, o->r, o->A, o->Bm,
-                   o->c, o->Qinv, o->Rinv, o->S, o->Pinv, o->gamma, o->dz, o->merit, o->merit_cur, o->merit_init0, o->step, o->st_min_merit, o->st_step, o->pcg_work};
+                   o->c, o->Qinv, o->Rinv, o->S, o->Pinv, o->gamma, o->dz, o->merit, o->merit_cur, o->merit_init0, o->step, o->st_min_merit, o->st_step, o->pcg_work, o->costw};
     for (size_t i = 0; i < sizeof(fl) / sizeof(fl[0]); i++) free(fl[i]);
     free(o->converged); free(o->pcg_iters); free(o->st_pcg_iters); free(o->sqp_iters); free(o->kkt_converged);
     free(o);
@@ -961,6 +967,8 @@ void orc_set_drho(Orc* o, const float* v, int as_default)
     memcpy(o->drho, v, o->B * sizeof(float));
 }
 void orc_set_mu(Orc* o, const float* v) { memcpy(o->mu, v, o->B * sizeof(float)); }
+/* [B][7] = q, qd, u, N, q_lim, vel_lim, ctrl_lim cost weights per trajectory */
+void orc_set_cost_weights(Orc* o, const float* v) { memcpy(o->costw, v, 7 * (size_t)o->B * sizeof(float)); }
 void orc_set_pcg_tol(Orc* o, const float* v) { memcpy(o->pcg_tol, v, o->B * sizeof(float)); }
 void orc_reset_dual(Orc* o) { memset(o->lambda, 0, (size_t)o->B * o->vecp * sizeof(float)); }
 void orc_reset_rho(Orc* o)

@@ -48,7 +48,7 @@ def lib():
         L.orc_buf.argtypes = [C.c_void_p, C.c_char_p]
         L.orc_ibuf.restype = C.POINTER(C.c_int32)
         L.orc_ibuf.argtypes = [C.c_void_p, C.c_char_p]
-        for name in ("orc_set_f_ext", "orc_set_mu", "orc_set_pcg_tol"):
+        for name in ("orc_set_f_ext", "orc_set_mu", "orc_set_pcg_tol", "orc_set_cost_weights"):
             getattr(L, name).argtypes = [C.c_void_p, fp]
         for name in ("orc_set_rho", "orc_set_drho"):
             getattr(L, name).argtypes = [C.c_void_p, fp, C.c_int]
@@ -112,6 +112,10 @@ class OracleSolver:
 
     def set_drho_batch(self, v, set_as_reset_default=True):
         a, p = _f(v); lib().orc_set_drho(self.h, p, int(set_as_reset_default))
+
+    def set_cost_weights_batch(self, w):
+        """w[B,7] = q, qd, u, N, q_lim, vel_lim, ctrl_lim cost weights per trajectory"""
+        a, p = _f(w); assert a.size == 7 * self.B; lib().orc_set_cost_weights(self.h, p)
 
     def set_mu_batch(self, v):
         a, p = _f(v); lib().orc_set_mu(self.h, p)

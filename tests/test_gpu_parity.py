@@ -291,6 +291,59 @@ def test_final_merit_is_the_merit_of_the_returned_iterates(plant, N, B):
     assert relscale(orc.merit(rg["XU"], pr["x_s"], pr["ref"], DT, num_alphas=1, zero_dz=True)[:, 0], final) < 1e-4
 
 
+def _sweep_weights(B, lims=False):
+    """B rows of the hyper-parameter grid as [q, qd, u, N, q_lim, vel_lim, ctrl_lim]"""
+    from gato_amd.bsqp.workloads import HPARAM_COST_GRID
+    w = np.zeros((B, 7), np.float32)
+    for i in range(B):
+        g = HPARAM_COST_GRID[(5 * i) % len(HPARAM_COST_GRID)]
+        w[i] = [g["q_cost"], g["qd_cost"], g["u_cost"], g["N_cost"], 0.01, 1e-3 if (lims and i % 2) else 0.0, 1e-4 if (lims and i % 3 == 0) else 0.0]
+    return w
+
+
+@pytest.mark.parametrize("plant,N,B", [("indy7", 32, 9), ("iiwa14", 16, 5)])
+def test_per_trajectory_cost_weights_parity(plant, N, B):
+    """Extension SURVEY 8(f)3: every trajectory with its own cost weights (incl. velocity / torque limit barriers switched on for some).
+    Stage outputs that depend on the weights (cost blocks, merit) and a whole iteration agree with the oracle."""
+    nat, orc, pr = make(plant, N, B, 2.0, max_sqp_iters=1, pcg_tol=1e-8, max_pcg_iters=600)
+    w = _sweep_weights(B, lims=True)
+    nat.set_cost_weights_batch(w)
+    orc.set_cost_weights_batch(w)
+    xu, xs, ref = pr["xu"], pr["x_s"], pr["ref"]
+    nat.stage("merit1", xu, DT, xs, ref)
+    assert relscale(nat.read("merit_cur"), orc.merit(xu, xs, ref, DT, num_alphas=1, zero_dz=True)[:, 0]) < 1e-5
+    nat.stage("kkt", xu, DT, xs, ref)
+    orc.setup_kkt(xu, xs, ref, DT)
+    assert rel(nat.read("q"), orc.buf("q").reshape(-1)) < 1e-5 and rel(nat.read("r"), orc.buf("r").reshape(-1)) < 1e-5
+    rg = nat.solve(xu, DT, xs, ref)
+    ro = orc.solve(xu, DT, xs, ref)
+    np.testing.assert_array_equal(rg["ls_step_size"], ro["ls_step_size"])
+    # the sweep's corner weights (qd_cost 1e-5, u_cost 1e-7) make the Schur system worse conditioned than the default set: 2e-3
+    assert traj_err(rg["XU"], ro["XU"]).max() < 2e-3, traj_err(rg["XU"], ro["XU"])
+
+
+def test_sweep_in_one_batch_equals_one_solver_per_tuple():
+    """Trajectories are independent, so a batch whose rows carry different cost weights must give, row by row, the bits of a solver
+    constructed with that row's weights as its scalars (the reference's way of running the sweep: one solver per tuple)."""
+    from gato_amd._lib import NativeSolver
+    N, B = 32, 12
+    p = dict(DEFAULT_SOLVER_PARAMS, max_sqp_iters=3)
+    pr = fig8_problem("indy7", N, B, f_ext_std=1.0)
+    w = _sweep_weights(B)
+    one = NativeSolver("indy7", N, B, dt=DT, **p)
+    one.set_f_ext_batch(pr["f_ext"])
+    one.set_cost_weights_batch(w)
+    r1 = one.solve(pr["xu"], DT, pr["x_s"], pr["ref"])
+    for i in range(B):
+        pi = dict(p, q_cost=float(w[i, 0]), qd_cost=float(w[i, 1]), u_cost=float(w[i, 2]), N_cost=float(w[i, 3]), q_lim_cost=float(w[i, 4]),
+                  vel_lim_cost=float(w[i, 5]), ctrl_lim_cost=float(w[i, 6]))
+        s = NativeSolver("indy7", N, 1, dt=DT, **pi)
+        s.set_f_ext_batch(pr["f_ext"][i:i + 1])
+        ri = s.solve(pr["xu"][i:i + 1], DT, pr["x_s"][i:i + 1], pr["ref"][i:i + 1])
+        np.testing.assert_array_equal(ri["XU"][0], r1["XU"][i])
+        np.testing.assert_array_equal(ri["final_merit"][0], r1["final_merit"][i])
+
+
 def test_sim_forward_and_ee_pos():
     from oracle import oracle as O
     nat, orc, pr = make("iiwa14", 8, 5, 4.0)

@@ -144,3 +144,26 @@ def test_sim_forward_uses_one_state_many_wrenches():
     # type-2 rule: qd+ = qd + dt qdd, q+ = q + dt qd + dt^2/2 qdd  (integrator.cuh:34-37)
     qdd = (out[0, 6:] - xk[6:]) / 0.01
     np.testing.assert_allclose(out[0, :6], xk[:6] + 0.01 * xk[6:] + 0.5 * 0.01 ** 2 * qdd, atol=1e-6)
+
+
+def test_per_trajectory_cost_weights_equal_one_solver_per_tuple():
+    """Extension SURVEY 8(f)3 in the oracle: a batch whose rows carry their own cost weights reproduces, row by row and bit for bit,
+    solvers constructed with those weights as scalars."""
+    import numpy as np
+    from gato_amd.bsqp.config import DEFAULT_SOLVER_PARAMS
+    from gato_amd.bsqp.workloads import HPARAM_COST_GRID, fig8_problem
+    from oracle.oracle import OracleSolver
+    N, B, dt = 8, 4, 0.01
+    p = dict(DEFAULT_SOLVER_PARAMS, max_sqp_iters=2)
+    pr = fig8_problem("indy7", N, B)
+    w = np.array([[g["q_cost"], g["qd_cost"], g["u_cost"], g["N_cost"], 0.01, 0.0, 1e-4 * (i % 2)] for i, g in
+                  enumerate(HPARAM_COST_GRID[3:3 + B])], np.float32)
+    one = OracleSolver("indy7", N, B, dt=dt, **p)
+    one.set_cost_weights_batch(w)
+    r1 = one.solve(pr["xu"], dt, pr["x_s"], pr["ref"])
+    for i in range(B):
+        pi = dict(p, q_cost=float(w[i, 0]), qd_cost=float(w[i, 1]), u_cost=float(w[i, 2]), N_cost=float(w[i, 3]), q_lim_cost=float(w[i, 4]),
+                  vel_lim_cost=float(w[i, 5]), ctrl_lim_cost=float(w[i, 6]))
+        s = OracleSolver("indy7", N, 1, dt=dt, **pi)
+        ri = s.solve(pr["xu"][i:i + 1], dt, pr["x_s"][i:i + 1], pr["ref"][i:i + 1])
+        np.testing.assert_array_equal(ri["XU"][0], r1["XU"][i])
