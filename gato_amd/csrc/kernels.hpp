@@ -205,10 +205,9 @@ GATO_DEV float seg_sum(float v, int seg, float* lds_part)
 // =========================================================================================================================
 // one lane's term of the merit function: knot k of trajectory b at xu + alpha dz (dzb: the trajectory's step, global or LDS)
 template<class M>
-GATO_DEV float merit_term(const Buffers& bf, int N, int b, int k, float alpha, int use_dz, const float* dzb, float dt)
+GATO_DEV float merit_term(const Buffers& bf, const Costs& cw, int N, int b, int k, float alpha, int use_dz, const float* dzb, float dt)
 {
     constexpr int NQ = M::NQ, NX = 2 * NQ, NU = NQ, KS = NX + NU;
-    const Costs cw = load_costs(bf, b);
     const int traj = KS * N - NU;
     const float* xu = bf.xu + (size_t)b * traj + (size_t)k * KS;
     const float* dz = dzb + (size_t)k * KS;
@@ -330,7 +329,7 @@ __global__ __launch_bounds__(256) void merit_kernel(Buffers bf, int N, int B, fl
     const bool live = b < B;
     if (!live) b = B - 1;
     const float alpha = (float)(1.0 / (double)(1 << ai));
-    float m = merit_term<M>(bf, N, b, k, alpha, use_dz, bf.dz + (size_t)b * (KS * N - NU), dt);
+    float m = merit_term<M>(bf, load_costs(bf, b), N, b, k, alpha, use_dz, bf.dz + (size_t)b * (KS * N - NU), dt);
     m = seg_sum(m, N, part);
     if (live && k == 0) out[b * NA + ai] = m;
 }
@@ -1877,6 +1876,7 @@ __global__ __launch_bounds__(512) void step_kernel(Buffers bf, int N, int B, flo
     float* dzs = lds;
     float* mer = lds + ((traj + 3) & ~3);
     if (b == 0 && t == 0) bf.ctrl->iters_done = sqp_iter + 1;
+    const Costs cw = load_costs(bf, b);  // fetched now, used after the dz phase: the latency hides behind it
     if (t < N) dz_knot<M, 1>(bf, N, b, t, dt, dzs);              // state rows
     else if (t < 2 * N) dz_knot<M, 2>(bf, N, b, t - N, dt, dzs);  // control rows
     // The loop breaks before the line search (bsqp.cuh:165); every workgroup takes the same branch.  `done` is raised by the NEXT
@@ -1886,7 +1886,7 @@ __global__ __launch_bounds__(512) void step_kernel(Buffers bf, int N, int B, flo
     {
         const int k = t % N, ai = t / N;
         const float alpha = (float)(1.0 / (double)(1 << ai));
-        float m = merit_term<M>(bf, N, b, k, alpha, 1, dzs, dt);
+        float m = merit_term<M>(bf, cw, N, b, k, alpha, 1, dzs, dt);
         m = seg_sum(m, N, nullptr);  // N <= 64: inside one wavefront
         if (k == 0) {
             mer[ai] = m;
