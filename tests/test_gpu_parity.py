@@ -332,6 +332,8 @@ def test_sweep_in_one_batch_equals_one_solver_per_tuple():
     w = _sweep_weights(B)
     one = NativeSolver("indy7", N, B, dt=DT, **p)
     one.set_f_ext_batch(pr["f_ext"])
+    with pytest.raises(ValueError):
+        one.set_cost_weights_batch(np.zeros((B, 6), np.float32))   # wrong shape: rejected on the host side
     one.set_cost_weights_batch(w)
     r1 = one.solve(pr["xu"], DT, pr["x_s"], pr["ref"])
     for i in range(B):
