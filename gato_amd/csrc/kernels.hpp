@@ -1168,7 +1168,7 @@ GATO_DEV float wave_sum(float v)
     GATO_DPP_ADD(0x140);  // row_mirror: every lane holds its row's sum
 #undef GATO_DPP_ADD
     // the four row sums through the scalar unit (independent v_readlane's) instead of two more dependent DPP steps:
-    // 52 vs 59 ns per reduction in isolation (tools/exp/wsum.hip)
+    // 52 vs 59 ns per reduction in isolation (tools/microbench/wave_sum.hip)
     const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
     const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
     const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
