@@ -524,54 +524,74 @@ GATO_DEV void kkt_costs(const Buffers& bf, const Costs& cw, const float* x, cons
 //   task NT-1    : the cost blocks of knot k; its lane k = N-1 produces the terminal blocks from x_{N-2} and c_0 = x_0 - x_s.
 // __launch_bounds__(64, 2): two wavefronts per SIMD.  A lone wavefront issues one dependent VALU instruction per ~10 cycles; the
 // second one fills the gaps, which pays for the few spills the 256-register budget costs.
-template<class M, int g> GATO_DEV void kkt_dispatch(int task, const Buffers& bf, const float* xu, const float* fe, size_t bk, float dt)
+template<class M, int g> GATO_DEV void kkt_dispatch(int task, const Buffers& bf, const float* xu, const float* fe, float* Dout, size_t bk, float dt)
 {
     constexpr int NQ = M::NQ, NX = 2 * NQ;
     if constexpr (g < (NQ + 1) / 2) {
         if (task == g)
-            kkt_columns<M, g, NQ - 1 - g>(bf.D + bk * 3 * NQ * NQ, bf.c + (bk + 1) * NX, xu, fe, dt);
+            kkt_columns<M, g, NQ - 1 - g>(Dout, bf.c + (bk + 1) * NX, xu, fe, dt);
         else
-            kkt_dispatch<M, g + 1>(task, bf, xu, fe, bk, dt);
+            kkt_dispatch<M, g + 1>(task, bf, xu, fe, Dout, bk, dt);
     }
 }
 
+// One workgroup = the NT tasks (wavefronts) of 64 consecutive knots.  The column tasks leave their pieces of D in LDS ([64][3 nq^2]);
+// after a barrier the whole workgroup copies the 64 blocks -- contiguous in global memory -- out with 16-byte stores of consecutive
+// lanes.  Written directly, every lane's 24-byte column pieces were separate 8-byte requests to different cache lines (54 per knot);
+// the request rate of those stores, not the arithmetic, bounded this kernel.
 template<class M>
-__global__ __launch_bounds__(64, 2) void kkt_kernel(Buffers bf, int N, int B, float dt, int sqp_iter, float thresh, int row0)
+__global__ __launch_bounds__(64 * ((M::NQ + 1) / 2 + 1), 2) void kkt_kernel(Buffers bf, int N, int B, float dt, int sqp_iter, float thresh, int row0)
 {
-    constexpr int NQ = M::NQ, NX = 2 * NQ, NU = NQ, KS = NX + NU, NT = (NQ + 1) / 2 + 1;
+    constexpr int NQ = M::NQ, NX = 2 * NQ, NU = NQ, KS = NX + NU, NT = (NQ + 1) / 2 + 1, ND = 3 * NQ * NQ;
+    extern __shared__ __attribute__((aligned(16))) float ldsD[];
     if (bf.ctrl->done) return;
     if (sqp_iter > 0 && (float)bf.num_solved[sqp_iter - 1] >= thresh) {
         // the previous iteration ended the loop (bsqp.cuh:165): raise `done` for everything that follows; whether a workgroup sees the
         // flag or the count, it leaves
-        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) bf.ctrl->done = 1;
+        if (blockIdx.x == 0 && threadIdx.x == 0) bf.ctrl->done = 1;
         return;
     }
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    const int k = g % N, b = g / N;
-    const int task = blockIdx.y;  // wave-uniform
-    if (b >= B) return;
+    const int lane = threadIdx.x & 63;
+    const int task = threadIdx.x >> 6;  // wave-uniform
+    const long total = (long)B * N;
+    const long g = (long)blockIdx.x * 64 + lane;
+    const bool valid = g < total;       // lanes past the batch shadow knot (0,0) and store nothing
+    const int k = valid ? (int)(g % N) : 0, b = valid ? (int)(g / N) : 0;
     const bool last = (k == N - 1);
-    if (last && task != NT - 1) return;
     const int traj = KS * N - NU;
     const int kx = last ? N - 2 : k;  // the terminal lane reads knot N-2
     const float* xu = bf.xu + (size_t)b * traj + (size_t)kx * KS;
     const size_t bk = (size_t)b * N + k;
+    float* Dl = ldsD + lane * ND;
     if (task != NT - 1) {
-        kkt_dispatch<M, 0>(task, bf, xu, bf.f_ext + 6 * b, bk, dt);
-        return;
+        if (valid && !last) {
+            kkt_dispatch<M, 0>(task, bf, xu, bf.f_ext + 6 * b, Dl, bk, dt);
+        } else if (task == 0) {
+            for (int i = 0; i < ND; i++) Dl[i] = 0.f;  // the last knot has no dynamics block: its slot stays zero
+        }
+    } else if (valid) {
+        float x[KS + NX];
+#pragma unroll
+        for (int i = 0; i < KS + NX; i++) x[i] = xu[i];
+        constexpr int BROW = 3 * NX * NX;
+        kkt_costs<M>(bf, load_costs(bf, b), x, bf.ref + (size_t)b * 6 * N + 6 * k, bk, bf.rho[b], last, row0 && k == 0, bf.x_s + (size_t)b * NX,
+                     bf.S + (size_t)b * N * BROW, bf.Pinv + (size_t)b * N * BROW, bf.gamma + (size_t)b * (N + 2) * NX);
+        if (last) {
+            float c0[NX];
+            const float* x0 = bf.xu + (size_t)b * traj;
+#pragma unroll
+            for (int i = 0; i < NX; i++) c0[i] = x0[i] - bf.x_s[(size_t)b * NX + i];
+            store_vec<NX, NX>(bf.c + (size_t)b * N * NX, c0);
+        }
     }
-    float x[KS + NX];
-#pragma unroll
-    for (int i = 0; i < KS + NX; i++) x[i] = xu[i];
-    constexpr int BROW = 3 * NX * NX;
-    kkt_costs<M>(bf, load_costs(bf, b), x, bf.ref + (size_t)b * 6 * N + 6 * k, bk, bf.rho[b], last, row0 && k == 0, bf.x_s + (size_t)b * NX,
-                 bf.S + (size_t)b * N * BROW, bf.Pinv + (size_t)b * N * BROW, bf.gamma + (size_t)b * (N + 2) * NX);
-    if (last) {
-        float c0[NX];
-        const float* x0 = bf.xu + (size_t)b * traj;
-#pragma unroll
-        for (int i = 0; i < NX; i++) c0[i] = x0[i] - bf.x_s[(size_t)b * NX + i];
-        store_vec<NX, NX>(bf.c + (size_t)b * N * NX, c0);
+    __syncthreads();
+    {
+        const long first = (long)blockIdx.x * 64;
+        const int cnt = (int)((total - first) < 64 ? (total - first) : 64);
+        const int nfl = cnt * ND, n4 = nfl / 4;
+        float* gD = bf.D + (size_t)first * ND;  // 64 ND floats per workgroup: 16-byte aligned
+        for (int i = threadIdx.x; i < n4; i += blockDim.x) reinterpret_cast<float4*>(gD)[i] = reinterpret_cast<const float4*>(ldsD)[i];
+        for (int i = 4 * n4 + threadIdx.x; i < nfl; i += blockDim.x) gD[i] = ldsD[i];
     }
 }
 

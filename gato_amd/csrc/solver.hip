@@ -194,8 +194,8 @@ template<class M> static void launch_kkt(GatoSolver* s, hipStream_t st, float dt
     // The same task split for EVERY batch size: it changes the generated code (and with it the last bit of D), so choosing it by
     // batch size would make a trajectory's iterates depend on how many neighbours it has.
     constexpr int NT = (M::NQ + 1) / 2 + 1;
-    hipLaunchKernelGGL((kkt_kernel<M>), dim3(cdiv((long)s->B * s->N, 64), NT), dim3(64), 0, st, s->bf, s->N, s->B, dt, sqp_iter,
-                       s->p.solve_ratio * (float)s->B, row0);
+    hipLaunchKernelGGL((kkt_kernel<M>), dim3(cdiv((long)s->B * s->N, 64)), dim3(64 * NT), (size_t)64 * 3 * M::NQ * M::NQ * sizeof(float), st, s->bf, s->N,
+                       s->B, dt, sqp_iter, s->p.solve_ratio * (float)s->B, row0);
 }
 template<class M> static bool pcg_folds_stair(const GatoSolver* s);
 template<class M> static void launch_schur(GatoSolver* s, hipStream_t st, float dt, bool force_stair = false)
