@@ -1,19 +1,24 @@
 // kernels.hpp -- CDNA4 (gfx950) kernels of the batched SQP iteration.  Included once per plant by solver.hip.
 //
-// Mapping (MI355X-first, not the reference's block-per-knot scheme):
-//   * assembly / merit / dz kernels: ONE LANE per (trajectory, knot[, alpha]) problem, 64 problems per wavefront, everything
-//     for that problem in registers (rbd.hpp); cross-knot sums (merit) are wave butterflies -> deterministic, no float atomics;
-//   * PCG: one workgroup per trajectory, one thread per row of the block-tridiagonal system, the thread's rows of S and P^-1
-//     live in REGISTERS for the whole solve (read from HBM exactly once; the reference re-reads both from global memory on
-//     every PCG iteration, pcg.cuh:100,119), vectors exchanged through LDS;
+// Mapping (MI355X-first, not the reference's block-per-knot scheme) -- three launches per SQP iteration:
+//   * kkt_kernel: ONE LANE per (trajectory, knot) with the rigid-body recursion in registers (rbd.hpp); the work of 64 knots is
+//     split by TASK over the wavefronts of a workgroup (pairs of derivative columns | cost blocks); D leaves through LDS, coalesced;
+//   * pcgc_kernel<.., FUSE>: one workgroup per trajectory, three rows of the block-tridiagonal system per thread.  The Schur
+//     complement is FORMED here by 4-lane groups (DPP pivot broadcast) and stays in registers together with the stair preconditioner
+//     for the whole PCG solve: S and P^-1 never reach global memory (the reference re-reads both on every PCG iteration,
+//     pcg.cuh:100,119); vectors are exchanged through LDS, dot products are DPP + one LDS slot per wavefront;
+//   * step_kernel: one workgroup per trajectory: dz -> merit at the 8 step sizes (lane = (alpha, knot), wave-butterfly sums:
+//     deterministic, no float atomics) -> line search -> xu, rho;
+//   * stand-alone forms of every stage (schurq/schur1/schur2, pcg(c)_kernel, dz, merit<8>, line_search) serve the stage tests, iiwa14
+//     (nx = 14) and N > 64;
 //   * the SQP loop has no host round trip: convergence counting and the solve_ratio early exit run on the device (Ctrl).
 //
-// Global layouts are trajectory-major like the reference's (linalg.cuh:545-672) so xu / x_s / ref / lambda / S / P^-1 / gamma are
-// byte-compatible with its buffers; KKT blocks are stored COMPACT:
+// Global layouts are trajectory-major like the reference's (linalg.cuh:545-672) so xu / x_s / ref / lambda / gamma (and S / P^-1 where
+// they are materialised) are byte-compatible with its buffers; KKT blocks are stored COMPACT:
 //   D    [b][k][3 nq^2]   = [dqdd/dq | dqdd/dqd | M^-1] col-major nq x 3nq   (A_k, B_k are functions of D and dt: A_elem/B_elem)
 //   Qq   [b][k][nq^2], Qd [b][k][nq]   Q_k = blkdiag(Qq, diag(Qd))   (the cost Hessian has no other non-zeros, indy7_plant.cuh:375-408)
 //   Rd   [b][k][nu]                     R_k = diag(Rd)
-//   q [b][k][nx], r [b][k][nu], c [b][k][nx]; after schur: Qqi/Qdi/Rdi hold the inverses (separate buffers: no RAW hazard)
+//   q [b][k][nx], r [b][k][nu], c [b][k][nx]; Qqi/Qdi/Rdi hold the inverses (separate buffers: no RAW hazard)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
