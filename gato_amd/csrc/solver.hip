@@ -224,9 +224,17 @@ template<class M, int RPT, int FORCE_WPS = 0> static bool try_pcgc(GatoSolver* s
         constexpr int WPS = FORCE_WPS ? FORCE_WPS : (REGS > 256 ? 1 : (REGS > 168 ? 2 : (REGS > 128 ? 3 : 4)));
         constexpr int MAXT = WPS * 256;                    // threads per block that still leave REGS registers per lane
         if (T > MAXT) return false;
-        if (fold)
-            hipLaunchKernelGGL((pcgc_kernel<M, RPT, MAXT, true>), dim3(s->B), dim3(T), lds + (size_t)2 * s->N * NX * NX * sizeof(float), st, s->bf,
-                               s->N, s->B, s->p.max_pcg_iters, sqp_iter, write_p, 0.f);
+        if (fold) {
+            const size_t total = lds + (size_t)2 * s->N * NX * NX * sizeof(float);
+            static size_t granted = 64 * 1024;  // per instantiation: dynamic LDS beyond the 64 KB default has to be asked for
+            if (total > granted) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pcgc_kernel<M, RPT, MAXT, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)total);
+                granted = total;
+            }
+            hipLaunchKernelGGL((pcgc_kernel<M, RPT, MAXT, true>), dim3(s->B), dim3(T), total, st, s->bf, s->N, s->B, s->p.max_pcg_iters, sqp_iter,
+                               write_p, 0.f);
+        }
         else
             hipLaunchKernelGGL((pcgc_kernel<M, RPT, MAXT, false>), dim3(s->B), dim3(T), lds, st, s->bf, s->N, s->B, s->p.max_pcg_iters, sqp_iter, 0,
                                0.f);
@@ -274,7 +282,8 @@ template<class M> static bool pcg_folds_stair(const GatoSolver* s)
     const int rows = s->N * s->nx;
     const bool regs_kernel = (NX % 2 == 0 && ((rows + 1) / 2 + 63) / 64 * 64 <= 512) || (NX % 3 == 0 && ((rows + 2) / 3 + 63) / 64 * 64 <= 256) ||
                              (NX % 6 == 0 && ((rows + 5) / 6 + 63) / 64 * 64 <= 256) || (v && atoi(v) == 6);
-    return regs_kernel && (size_t)2 * s->N * NX * NX * sizeof(float) <= 56 * 1024;  // stays under the 64 KB default dynamic-LDS limit
+    // the two fold buffers + the vectors must fit one CU's 160 KB of LDS (beyond 64 KB the kernel asks for it: try_pcgc)
+    return regs_kernel && (size_t)2 * s->N * NX * NX * sizeof(float) + (size_t)(2 * s->vecp + 36) * sizeof(float) <= 150 * 1024;
 }
 
 template<class M> static void launch_pcg(GatoSolver* s, hipStream_t st, int sqp_iter, int write_p = 0)
