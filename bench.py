@@ -144,14 +144,13 @@ def main():
     params = dict(DEFAULT_SOLVER_PARAMS, max_sqp_iters=a.sqp_iters)
     pr = fig8_problem(plant, N, B, batch_offset=rank * B)          # rank r owns rows [r*B, (r+1)*B) of the global batch
     solver = NativeSolver(plant, N, B, dt=dt, **params)
+    from gato_amd.sharding import PackedResults, check_sharded_params
+    check_sharded_params(params["solve_ratio"], world)
     xu0 = torch.from_numpy(pr["xu"]).to(dev)
-    xu = torch.empty_like(xu0)
     x_s = torch.from_numpy(pr["x_s"]).to(dev)
     ref = torch.from_numpy(pr["ref"]).to(dev)
-    merit = torch.empty(B, dtype=torch.float32, device=dev)
-    if world > 1:
-        g_xu = [torch.empty_like(xu) for _ in range(world)]
-        g_merit = [torch.empty_like(merit) for _ in range(world)]
+    pk = PackedResults(B, solver.traj, world, dev)  # [B*TRAJ iterates | B merits], solved in place, gathered by ONE collective
+    xu, merit = pk.xu, pk.merit
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():
@@ -159,9 +158,7 @@ def main():
         xu.copy_(xu0)
         solver.solve_device(xu.data_ptr(), dt, x_s.data_ptr(), ref.data_ptr(), stream)
         solver.copy_final_merit_device(merit.data_ptr(), stream)
-        if world > 1:
-            dist.all_gather(g_xu, xu)           # iterates: B x TRAJ fp32 per rank over xGMI
-            dist.all_gather(g_merit, merit)     # costs: B fp32 per rank
+        pk.all_gather()                         # iterates + costs: (B x TRAJ + B) fp32 per rank over xGMI (no-op on one GPU)
 
     def sync():
         if world > 1:

@@ -17,6 +17,7 @@ SYMBOLS = [
     "gato_set_mu_batch", "gato_set_pcg_tol_batch", "gato_reset_dual", "gato_reset_rho", "gato_set_rho_adaptation", "gato_sim_forward",
     "gato_ee_pos", "gato_debug_read", "gato_debug_write", "gato_debug_stage", "gato_set_profiling", "gato_get_stage_times_us",
     "gato_last_error", "gato_version", "gato_reset_async", "gato_copy_final_merit_device", "gato_set_cost_weights_batch",
+    "gato_synchronize", "gato_sim_forward_device",
 ]
 
 
@@ -77,6 +78,8 @@ def load():
     L.gato_get_stage_times_us.argtypes = [vp, C.POINTER(C.c_double)]
     L.gato_reset_async.argtypes = [vp, C.c_int, C.c_int, vp]
     L.gato_copy_final_merit_device.argtypes = [vp, vp, vp]
+    L.gato_synchronize.argtypes = [vp]
+    L.gato_sim_forward_device.argtypes = [vp, vp, vp, vp, C.c_float, vp]
     L.gato_last_error.restype = C.c_char_p
     L.gato_version.restype = C.c_char_p
     _lib = L
@@ -223,6 +226,13 @@ class NativeSolver:
         out = np.zeros((self.B, self.nx), np.float32)
         _chk(load().gato_sim_forward(self.h, _p(out), _p(_f32(xk, (self.nx,))), _p(_f32(uk, (self.nu,))), float(dt)))
         return out
+
+    def sim_forward_device(self, d_xkp1, d_xk, d_uk, dt, stream=0):
+        """BSQP::sim_forward on raw device pointers (ints), asynchronous on `stream` (bsqp.cuh:91)."""
+        _chk(load().gato_sim_forward_device(self.h, C.c_void_p(d_xkp1), C.c_void_p(d_xk), C.c_void_p(d_uk), float(dt), C.c_void_p(stream)))
+
+    def synchronize(self):
+        _chk(load().gato_synchronize(self.h))
 
     def ee_pos(self, q):
         q = _f32(q).reshape(-1, self.nq)

@@ -31,6 +31,7 @@ constexpr int NUM_ALPHAS = 8;        // settings.h:16
 constexpr float RHO_FACTOR = 1.2f;   // settings.h:20
 constexpr float RHO_MIN = 1e-8f;     // settings.h:21
 constexpr float RHO_MAX = 10.0f;     // settings.h:22
+constexpr float RHO_INIT = 1e-3f;    // settings.h:18
 
 // Cost weights of ONE trajectory.  The reference has one scalar set per solver (bsqp.cuh:344-350); here they live per trajectory
 // (Buffers::costw, [B][8] floats, filled from the solver's scalars unless gato_set_cost_weights_batch overrides them) so that a
@@ -1864,6 +1865,9 @@ GATO_DEV void line_search_block(const Buffers& bf, int b, int B, int traj, const
             r = fminf(r, RHO_MAX);
             bf.rho[b] = r;
         }
+        // line_search.cuh:77-79: a failed search resets rho > RHO_MAX to RHO_INIT -- dead after the clamp above, live when
+        // adaptation is off and the caller's rho_batch exceeds RHO_MAX
+        if (!success && bf.rho[b] > RHO_MAX) bf.rho[b] = RHO_INIT;
         float step = -1.f;
         if (success) {
             step = (float)(1.0 / (double)(1 << idx));

@@ -31,6 +31,22 @@ static int fail(int code, const std::string& msg)
 
 enum Stage { ST_MERIT = 0, ST_KKT, ST_SCHUR, ST_PCG, ST_DZ, ST_LS, ST_COUNT };
 
+// A handle is bound to the HIP device that was current at gato_create: every ABI entry makes that device current for its
+// duration and restores the caller's afterwards (a host that drives several GPUs from one thread switches devices between calls).
+struct DeviceGuard {
+    int prev = -1, want = -1;
+    explicit DeviceGuard(int dev) : want(dev)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != want) (void)hipSetDevice(want);
+    }
+    ~DeviceGuard()
+    {
+        if (prev >= 0 && prev != want) (void)hipSetDevice(prev);
+    }
+};
+#define GUARD(s) DeviceGuard guard_((s)->device)
+
 struct GatoSolver {
     int plant, N, B, nq, nx, nu, traj, vecp, brow;
     int device;
@@ -43,11 +59,19 @@ struct GatoSolver {
     int fuse_schur;  // Schur complement formed inside the PCG kernel (GATO_SCHUR_FUSED, default 1)
     int fuse_step;   // dz + merit + line search in one launch (GATO_STEP_FUSED, default 1); both are read when the solver is created
     int schur_rowlane;  // stand-alone Schur kernel with one row per lane (GATO_SCHUR_ROWLANE; default: nq odd)
+    // the PCG launch plan, decided ONCE when the solver is created (plan_pcg): which register-resident kernel runs (0 = the
+    // streaming pcg_kernel), whether it forms the stair off-diagonals itself (then schur2_kernel is not launched) and whether the
+    // Schur complement is formed inside it.  Tuning overrides GATO_PCG_VARIANT / GATO_PCG_FOLD are read there, never in the solve loop.
+    int pcg_choice, pcg_fold, pcg_fused;
+    float *d_sim_x, *d_sim_u, *d_sim_out;  // staging of sim_forward ([nx], [nu], [B][nx]), allocated with the solver
+    float *d_ee_q, *d_ee_out;              // staging of ee_pos, grown on demand
+    size_t ee_cap;
     uint32_t max_iters_alloc;
     Buffers bf;
-    float *d_xu_own, *d_xs_own, *d_ref_own, *d_merit_init0, *d_drho_init, *d_rho_init, *d_scratch_B;
+    float *d_xu_own, *d_xs_own, *d_ref_own, *d_merit_init0, *d_drho_init, *d_rho_init;
     std::vector<float> h_rho_init, h_drho_init;
     hipStream_t last_stream;
+    bool last_stream_valid = false;  // a solve has been enqueued on last_stream (it may be the caller's stream)
     std::vector<void*> allocs;
     // profiling
     int profiling;
@@ -86,15 +110,10 @@ extern "C" int gato_dims(int plant, int N, int* nq, int* nx, int* nu, int* traj)
     return GATO_OK;
 }
 
-extern "C" int gato_create(int plant, int N, int B, const GatoParams* params, GatoSolver** out)
+static int plan_pcg_dispatch(GatoSolver* s);
+
+static int create_impl(GatoSolver* s, int plant, int N, int B, const GatoParams* params)
 {
-    if (!out || !params) return fail(GATO_ERR_INVALID, "null argument");
-    if (plant != GATO_PLANT_INDY7 && plant != GATO_PLANT_IIWA14) return fail(GATO_ERR_INVALID, "unknown plant");
-    if (N < 4 || N > 256 || (N & (N - 1))) return fail(GATO_ERR_INVALID, "knot_points must be a power of two in [4, 256]");
-    if (B < 1) return fail(GATO_ERR_INVALID, "batch must be >= 1");
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(GATO_ERR_NO_DEVICE, "no HIP device visible");
-    GatoSolver* s = new GatoSolver();
     s->plant = plant; s->N = N; s->B = B;
     gato_dims(plant, N, &s->nq, &s->nx, &s->nu, &s->traj);
     s->vecp = (N + 2) * s->nx;
@@ -115,7 +134,7 @@ extern "C" int gato_create(int plant, int N, int B, const GatoParams* params, Ga
     Buffers& bf = s->bf;
     memset(&bf, 0, sizeof(bf));
     int rc;
-#define DA(ptr, n) if ((rc = dalloc(s, &(ptr), (n))) != GATO_OK) { gato_destroy(s); return rc; }
+#define DA(ptr, n) if ((rc = dalloc(s, &(ptr), (n))) != GATO_OK) return rc;
     DA(bf.lambda, (size_t)B * s->vecp);
     DA(bf.rho, B); DA(bf.drho, B); DA(bf.mu, B); DA(bf.pcg_tol, B); DA(bf.f_ext, 6 * (size_t)B);
     { float* cwp = nullptr; DA(cwp, 8 * (size_t)B); s->d_costw = cwp; bf.costw = cwp; }
@@ -141,8 +160,11 @@ extern "C" int gato_create(int plant, int N, int B, const GatoParams* params, Ga
     DA(bf.st_pcg_iters, (size_t)s->max_iters_alloc * B); DA(bf.st_min_merit, (size_t)s->max_iters_alloc * B);
     DA(bf.st_step, (size_t)s->max_iters_alloc * B);
     DA(s->d_xu_own, (size_t)B * s->traj); DA(s->d_xs_own, (size_t)B * nx); DA(s->d_ref_own, (size_t)B * 6 * N);
-    DA(s->d_merit_init0, B); DA(s->d_drho_init, B); DA(s->d_rho_init, B); DA(s->d_scratch_B, (size_t)B * nx);
+    DA(s->d_merit_init0, B); DA(s->d_drho_init, B); DA(s->d_rho_init, B);
+    DA(s->d_sim_x, nx); DA(s->d_sim_u, nu); DA(s->d_sim_out, (size_t)B * nx);
 #undef DA
+    s->d_ee_q = s->d_ee_out = nullptr;
+    s->ee_cap = 0;
     // per-trajectory defaults (bsqp.cuh:48-58)
     s->h_rho_init.assign(B, params->rho);
     s->h_drho_init.assign(B, 1.0f);
@@ -163,6 +185,25 @@ extern "C" int gato_create(int plant, int N, int B, const GatoParams* params, Ga
         HIPCHK(hipMemcpy(s->d_costw, w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice));
     }
     HIPCHK(hipDeviceSynchronize());
+    return plan_pcg_dispatch(s);
+}
+
+extern "C" int gato_create(int plant, int N, int B, const GatoParams* params, GatoSolver** out)
+{
+    if (!out || !params) return fail(GATO_ERR_INVALID, "null argument");
+    if (plant != GATO_PLANT_INDY7 && plant != GATO_PLANT_IIWA14) return fail(GATO_ERR_INVALID, "unknown plant");
+    if (N < 4 || N > 256 || (N & (N - 1))) return fail(GATO_ERR_INVALID, "knot_points must be a power of two in [4, 256]");
+    if (B < 1) return fail(GATO_ERR_INVALID, "batch must be >= 1");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(GATO_ERR_NO_DEVICE, "no HIP device visible");
+    GatoSolver* s = new GatoSolver();
+    const int rc = create_impl(s, plant, N, B, params);
+    if (rc != GATO_OK) {
+        const std::string msg = g_err;  // gato_destroy must not clobber the reason
+        gato_destroy(s);
+        g_err = msg;
+        return rc;
+    }
     *out = s;
     return GATO_OK;
 }
@@ -170,6 +211,10 @@ extern "C" int gato_create(int plant, int N, int B, const GatoParams* params, Ga
 extern "C" int gato_destroy(GatoSolver* s)
 {
     if (!s) return GATO_OK;
+    GUARD(s);
+    if (s->last_stream_valid) (void)hipStreamSynchronize(s->last_stream);
+    if (s->d_ee_q) (void)hipFree(s->d_ee_q);
+    if (s->d_ee_out) (void)hipFree(s->d_ee_out);
     for (void* p : s->allocs) (void)hipFree(p);
     for (hipEvent_t e : s->events) (void)hipEventDestroy(e);
     delete s;
@@ -197,7 +242,101 @@ template<class M> static void launch_kkt(GatoSolver* s, hipStream_t st, float dt
     hipLaunchKernelGGL((kkt_kernel<M>), dim3(cdiv((long)s->B * s->N, 64)), dim3(64 * NT), (size_t)64 * 3 * M::NQ * M::NQ * sizeof(float), st, s->bf, s->N,
                        s->B, dt, sqp_iter, s->p.solve_ratio * (float)s->B, row0);
 }
-template<class M> static bool pcg_folds_stair(const GatoSolver* s);
+// ---- the PCG launch plan ------------------------------------------------------------------------------------------------
+// Register-resident kernels pcgc_kernel<M, RPT, MAXT, FOLD[, FUSE]>, tried in the order below; choice ids:
+//   4: <2 rows, 3 waves/SIMD>   6: <1 row>   5: <3 rows, 2 waves/SIMD>   2: <3 rows>   3: <2 rows>   1: <6 rows>   0: streaming pcg_kernel
+// Measured at indy7 N=32 B=1024 (profiles/r01d_pcg_variants.txt): 3 rows/thread 151 us, 2 rows 172 us, 1 row 213 us, 6 rows (one wave
+// per trajectory) 217 us per launch.  3 rows per thread first: 256 registers without spills = two wavefronts per SIMD = four 2-wave
+// trajectories per CU, so all 1024 trajectories of C2 are resident at once.
+template<int NX, int RPT, int FORCE_WPS> struct PcgcShape {
+    static constexpr int REGS = RPT * 6 * NX + 48;  // matrix rows + working set, per lane
+    static constexpr int WPS = FORCE_WPS ? FORCE_WPS : (REGS > 256 ? 1 : (REGS > 168 ? 2 : (REGS > 128 ? 3 : 4)));
+    static constexpr int MAXT = WPS * 256;          // threads per block that still leave REGS registers per lane
+    static int threads(int rows) { return (((rows + RPT - 1) / RPT + 63) / 64) * 64; }
+};
+static size_t pcg_vec_lds(const GatoSolver* s) { return (size_t)(2 * s->vecp + 36) * sizeof(float); }
+static size_t pcg_fold_lds(const GatoSolver* s) { return (size_t)2 * s->N * s->nx * s->nx * sizeof(float); }
+
+// Dynamic LDS beyond the 64 KB default has to be asked for, per function and device; the status is checked (a refused request
+// would otherwise turn into a failed launch reported iterations later).
+static bool grant_lds(const void* fn, size_t bytes)
+{
+    if (bytes <= 64 * 1024) return true;
+    if (bytes > 160 * 1024) return false;
+    return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess;
+}
+
+template<class M, int RPT, int FORCE_WPS = 0> static bool pcgc_fits(const GatoSolver* s)
+{
+    constexpr int NX = 2 * M::NQ;
+    if constexpr (NX % RPT != 0) {
+        return false;
+    } else {
+        using Sh = PcgcShape<NX, RPT, FORCE_WPS>;
+        return Sh::threads(s->N * s->nx) <= Sh::MAXT;
+    }
+}
+template<class M, int RPT, int FORCE_WPS = 0> static bool pcgc_grant_fold(const GatoSolver* s)
+{
+    constexpr int NX = 2 * M::NQ;
+    if constexpr (NX % RPT != 0) {
+        return false;
+    } else {
+        using Sh = PcgcShape<NX, RPT, FORCE_WPS>;
+        return grant_lds(reinterpret_cast<const void*>(&pcgc_kernel<M, RPT, Sh::MAXT, true>), pcg_vec_lds(s) + pcg_fold_lds(s));
+    }
+}
+template<class M> static size_t pcg_fused_lds(const GatoSolver* s)
+{
+    // LDS behind the vectors: the two fold buffers [N][nx][nx], later reused to park 3 x nx/4 float4 per thread (the larger for N < 8,
+    // where the workgroup is padded to one wavefront)
+    constexpr int NX = 2 * M::NQ;
+    const int T = PcgcShape<NX, 3, 0>::threads(s->N * s->nx);
+    const size_t fold = pcg_fold_lds(s), park = (size_t)3 * (NX / 4) * T * 4 * sizeof(float);
+    return pcg_vec_lds(s) + (fold > park ? fold : park);
+}
+
+template<class M> static int plan_pcg(GatoSolver* s)
+{
+    constexpr int NX = 2 * M::NQ;
+    const char* e = getenv("GATO_PCG_VARIANT");  // test / tuning override: 0 streaming, 1 RPT=6, 2 RPT=3, 3 RPT=2, 4..6 see above
+    const int v = e ? atoi(e) : 100;
+    const char* f = getenv("GATO_PCG_FOLD");
+    const bool fold_wanted = !(f && atoi(f) == 0);
+    int choice = 0;
+    if (v == 4 && pcgc_fits<M, 2, 3>(s)) choice = 4;
+    else if (v == 6 && pcgc_fits<M, 1>(s)) choice = 6;
+    else if (v == 5 && pcgc_fits<M, 3, 2>(s)) choice = 5;
+    else if ((v == 100 || v == 2) && pcgc_fits<M, 3>(s)) choice = 2;
+    else if ((v == 100 || v == 3) && pcgc_fits<M, 2>(s)) choice = 3;
+    else if ((v == 100 || v == 1) && pcgc_fits<M, 6>(s)) choice = 1;
+    s->pcg_choice = choice;
+    // the kernel that will run forms the stair off-diagonals itself when the two fold buffers + the vectors fit one CU's LDS and the
+    // runtime grants them; otherwise schur2_kernel is launched (launch_schur) and the kernel reads the complete P^-1
+    bool fold = fold_wanted && choice != 0 && pcg_vec_lds(s) + pcg_fold_lds(s) <= 150 * 1024;
+    if (fold) {
+        switch (choice) {
+            case 4: fold = pcgc_grant_fold<M, 2, 3>(s); break;
+            case 6: fold = pcgc_grant_fold<M, 1>(s); break;
+            case 5: fold = pcgc_grant_fold<M, 3, 2>(s); break;
+            case 2: fold = pcgc_grant_fold<M, 3>(s); break;
+            case 3: fold = pcgc_grant_fold<M, 2>(s); break;
+            case 1: fold = pcgc_grant_fold<M, 6>(s); break;
+        }
+    }
+    s->pcg_fold = fold ? 1 : 0;
+    // Schur complement formed inside the PCG kernel (pcgc_kernel<.., FUSE>): nx = 12 (3 rows per thread = the rows of one lane of a
+    // 4-lane Schur group), the trajectory in <= 256 threads, stair fold available.  GATO_SCHUR_FUSED=0 keeps the launches apart.
+    bool fused = false;
+    if constexpr (NX == 12) {
+        fused = s->fuse_schur && fold && choice == 2 && PcgcShape<NX, 3, 0>::threads(s->N * s->nx) <= 256;
+        if (fused) fused = grant_lds(reinterpret_cast<const void*>(&pcgc_kernel<M, 3, 256, true, true>), pcg_fused_lds<M>(s));
+    }
+    s->pcg_fused = fused ? 1 : 0;
+    return GATO_OK;
+}
+static int plan_pcg_dispatch(GatoSolver* s) { return s->plant == GATO_PLANT_INDY7 ? plan_pcg<Indy7>(s) : plan_pcg<Iiwa14>(s); }
+
 template<class M> static void launch_schur(GatoSolver* s, hipStream_t st, float dt, bool force_stair = false)
 {
     // lanes per (b,k): 4 with rows 3l..3l+2 (indy7); nq odd (iiwa14) divides evenly only into 2 x 7 rows -- heavier on registers
@@ -208,105 +347,47 @@ template<class M> static void launch_schur(GatoSolver* s, hipStream_t st, float 
         hipLaunchKernelGGL((schur1_kernel<M>), dim3(cdiv(probs * 16, 256), 2), dim3(256), 0, st, s->bf, s->N, s->B, dt);
     else
         hipLaunchKernelGGL((schurq_kernel<M, LPP>), dim3(cdiv(probs * LPP, 256), 2), dim3(256), 0, st, s->bf, s->N, s->B, dt);
-    if (force_stair || !pcg_folds_stair<M>(s)) hipLaunchKernelGGL((schur2_kernel<M>), dim3(cdiv(probs, 64)), dim3(64), 0, st, s->bf, s->N, s->B);
+    if (force_stair || !s->pcg_fold) hipLaunchKernelGGL((schur2_kernel<M>), dim3(cdiv(probs, 64)), dim3(64), 0, st, s->bf, s->N, s->B);
 }
-static int g_pcg_variant = -1;  // test / tuning override (GATO_PCG_VARIANT): 0 strided rows, 1 RPT=6, 2 RPT=3, 3 RPT=2
 
-template<class M, int RPT, int FORCE_WPS = 0> static bool try_pcgc(GatoSolver* s, hipStream_t st, int sqp_iter, size_t lds, bool fold, int write_p)
+template<class M, int RPT, int FORCE_WPS = 0> static void launch_pcgc(GatoSolver* s, hipStream_t st, int sqp_iter, int write_p)
 {
     constexpr int NX = 2 * M::NQ;
-    if constexpr (NX % RPT != 0) {
-        return false;
-    } else {
-        const int rows = s->N * s->nx;
-        const int T = (((rows + RPT - 1) / RPT + 63) / 64) * 64;
-        constexpr int REGS = RPT * 6 * NX + 48;            // matrix rows + working set, per lane
-        constexpr int WPS = FORCE_WPS ? FORCE_WPS : (REGS > 256 ? 1 : (REGS > 168 ? 2 : (REGS > 128 ? 3 : 4)));
-        constexpr int MAXT = WPS * 256;                    // threads per block that still leave REGS registers per lane
-        if (T > MAXT) return false;
-        if (fold) {
-            const size_t total = lds + (size_t)2 * s->N * NX * NX * sizeof(float);
-            static size_t granted = 64 * 1024;  // per instantiation: dynamic LDS beyond the 64 KB default has to be asked for
-            if (total > granted) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pcgc_kernel<M, RPT, MAXT, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          (int)total);
-                granted = total;
-            }
-            hipLaunchKernelGGL((pcgc_kernel<M, RPT, MAXT, true>), dim3(s->B), dim3(T), total, st, s->bf, s->N, s->B, s->p.max_pcg_iters, sqp_iter,
-                               write_p, 0.f);
-        }
+    if constexpr (NX % RPT == 0) {
+        using Sh = PcgcShape<NX, RPT, FORCE_WPS>;
+        const int T = Sh::threads(s->N * s->nx);
+        if (s->pcg_fold)
+            hipLaunchKernelGGL((pcgc_kernel<M, RPT, Sh::MAXT, true>), dim3(s->B), dim3(T), pcg_vec_lds(s) + pcg_fold_lds(s), st, s->bf, s->N, s->B,
+                               s->p.max_pcg_iters, sqp_iter, write_p, 0.f);
         else
-            hipLaunchKernelGGL((pcgc_kernel<M, RPT, MAXT, false>), dim3(s->B), dim3(T), lds, st, s->bf, s->N, s->B, s->p.max_pcg_iters, sqp_iter, 0,
-                               0.f);
-        return true;
+            hipLaunchKernelGGL((pcgc_kernel<M, RPT, Sh::MAXT, false>), dim3(s->B), dim3(T), pcg_vec_lds(s), st, s->bf, s->N, s->B,
+                               s->p.max_pcg_iters, sqp_iter, 0, 0.f);
     }
 }
 
-// Schur complement formed inside the PCG kernel (pcgc_kernel<.., FUSE>): nx = 12 (3 rows per thread = the rows of one lane of a 4-lane
-// Schur group), the trajectory in <= 256 threads, stair fold available.  GATO_SCHUR_FUSED=0 (read when the solver is created) keeps
-// the two launches apart.
-template<class M> static bool schur_fused(const GatoSolver* s)
-{
-    constexpr int NX = 2 * M::NQ;
-    if constexpr (NX != 12) {
-        return false;
-    } else {
-        const int rows = s->N * s->nx;
-        const char* v = getenv("GATO_PCG_VARIANT");
-        if (v && atoi(v) != 100 && atoi(v) != 2) return false;
-        return s->fuse_schur && ((rows + 2) / 3 + 63) / 64 * 64 <= 256 && pcg_folds_stair<M>(s);
-    }
-}
 template<class M> static void launch_pcg_fused(GatoSolver* s, hipStream_t st, float dt, int sqp_iter)
 {
     constexpr int NX = 2 * M::NQ;
     if constexpr (NX == 12) {
-        const int rows = s->N * s->nx;
-        const int T = (((rows + 2) / 3 + 63) / 64) * 64;
-        // LDS behind the vectors: the two fold buffers [N][nx][nx], later reused to park 3 x nx/4 float4 per thread (the larger for N < 8,
-        // where the workgroup is padded to one wavefront)
-        const size_t fold = (size_t)2 * s->N * NX * NX * sizeof(float), park = (size_t)3 * (NX / 4) * T * 4 * sizeof(float);
-        const size_t lds = (size_t)(2 * s->vecp + 36) * sizeof(float) + (fold > park ? fold : park);
-        hipLaunchKernelGGL((pcgc_kernel<M, 3, 256, true, true>), dim3(s->B), dim3(T), lds, st, s->bf, s->N, s->B, s->p.max_pcg_iters, sqp_iter, 0, dt);
+        const int T = PcgcShape<NX, 3, 0>::threads(s->N * s->nx);
+        hipLaunchKernelGGL((pcgc_kernel<M, 3, 256, true, true>), dim3(s->B), dim3(T), pcg_fused_lds<M>(s), st, s->bf, s->N, s->B,
+                           s->p.max_pcg_iters, sqp_iter, 0, dt);
     }
-}
-
-// true when the PCG kernel that will run forms the stair off-diagonals itself (then schur2_kernel is not launched)
-template<class M> static bool pcg_folds_stair(const GatoSolver* s)
-{
-    constexpr int NX = 2 * M::NQ;
-    const char* e = getenv("GATO_PCG_FOLD");
-    if (e && atoi(e) == 0) return false;
-    const char* v = getenv("GATO_PCG_VARIANT");
-    if (v && atoi(v) == 0) return false;
-    const int rows = s->N * s->nx;
-    const bool regs_kernel = (NX % 2 == 0 && ((rows + 1) / 2 + 63) / 64 * 64 <= 512) || (NX % 3 == 0 && ((rows + 2) / 3 + 63) / 64 * 64 <= 256) ||
-                             (NX % 6 == 0 && ((rows + 5) / 6 + 63) / 64 * 64 <= 256) || (v && atoi(v) == 6);
-    // the two fold buffers + the vectors must fit one CU's 160 KB of LDS (beyond 64 KB the kernel asks for it: try_pcgc)
-    return regs_kernel && (size_t)2 * s->N * NX * NX * sizeof(float) + (size_t)(2 * s->vecp + 36) * sizeof(float) <= 150 * 1024;
 }
 
 template<class M> static void launch_pcg(GatoSolver* s, hipStream_t st, int sqp_iter, int write_p = 0)
 {
-    const bool fold = pcg_folds_stair<M>(s);
     const int rows = s->N * s->nx;
-    const size_t lds = (size_t)(2 * s->vecp + 36) * sizeof(float);
-    if (g_pcg_variant < 0) {
-        const char* e = getenv("GATO_PCG_VARIANT");
-        g_pcg_variant = e ? atoi(e) : 100;
+    const size_t lds = pcg_vec_lds(s);
+    switch (s->pcg_choice) {
+        case 4: launch_pcgc<M, 2, 3>(s, st, sqp_iter, write_p); return;
+        case 6: launch_pcgc<M, 1>(s, st, sqp_iter, write_p); return;
+        case 5: launch_pcgc<M, 3, 2>(s, st, sqp_iter, write_p); return;
+        case 2: launch_pcgc<M, 3>(s, st, sqp_iter, write_p); return;
+        case 3: launch_pcgc<M, 2>(s, st, sqp_iter, write_p); return;
+        case 1: launch_pcgc<M, 6>(s, st, sqp_iter, write_p); return;
+        default: break;
     }
-    const int v = g_pcg_variant;
-    // register-resident, contiguous rows: the fewest waves per trajectory that fit the register file
-    // measured at indy7 N=32 B=1024 (profiles/r01d_pcg_variants.txt): 3 rows/thread 151 us, 2 rows 172 us, 1 row 213 us, 6 rows (one
-    // wave per trajectory) 217 us per launch
-    if (v == 4 && try_pcgc<M, 2, 3>(s, st, sqp_iter, lds, fold, write_p)) return;
-    if (v == 6 && try_pcgc<M, 1>(s, st, sqp_iter, lds, fold, write_p)) return;     // 1 row/thread, 6 waves per indy7 N=32 trajectory
-    if (v == 5 && try_pcgc<M, 3, 2>(s, st, sqp_iter, lds, fold, write_p)) return;  // 3 rows/thread in 256 registers
-    // 3 rows per thread first: 256 registers without spills = two wavefronts per SIMD = four 2-wave trajectories per CU, so all
-    // 1024 trajectories of C2 are resident at once (2 rows per thread: 200+ registers, two trajectories per CU, two rounds)
-    if ((v == 100 || v == 2) && try_pcgc<M, 3>(s, st, sqp_iter, lds, fold, write_p)) return;
-    if ((v == 100 || v == 3) && try_pcgc<M, 2>(s, st, sqp_iter, lds, fold, write_p)) return;
-    if ((v == 100 || v == 1) && try_pcgc<M, 6>(s, st, sqp_iter, lds, fold, write_p)) return;
     const int T1 = ((rows + 63) / 64) * 64;
     if (T1 <= 512) {
         hipLaunchKernelGGL((pcg_kernel<M, 1, false, 512>), dim3(s->B), dim3(T1), lds, st, s->bf, s->N, s->B, s->p.max_pcg_iters, sqp_iter);
@@ -366,6 +447,7 @@ template<class M> static int solve_impl(GatoSolver* s, float* d_xu, float dt, co
     const int B = s->B;
     bf.xu = d_xu; bf.x_s = d_xs; bf.ref = d_ref;
     s->last_stream = st;
+    s->last_stream_valid = true;
     size_t ei = 0;
     // bsqp.cuh:112-114 (+ the device-side loop control)
     HIPCHK(hipMemsetAsync(s->zero_slab, 0, s->zero_words * sizeof(float), st));  // dz, pcg_iters, converged, ctrl, num_solved
@@ -375,7 +457,7 @@ template<class M> static int solve_impl(GatoSolver* s, float* d_xu, float dt, co
     mark(s, st, ST_MERIT, ei);
     const uint32_t iters = s->p.max_sqp_iters <= s->max_iters_alloc ? s->p.max_sqp_iters : s->max_iters_alloc;
     for (uint32_t it = 0; it < iters; it++) {
-        const bool fused = schur_fused<M>(s);
+        const bool fused = s->pcg_fused != 0;
         launch_kkt<M>(s, st, dt, (int)it, fused ? 1 : 0);
         mark(s, st, ST_KKT, ei);
         if (fused) {
@@ -426,12 +508,14 @@ static void collect_profile(GatoSolver* s)
 extern "C" int gato_solve_device(GatoSolver* s, float* d_xu, float dt, const float* d_xs, const float* d_ref, void* stream)
 {
     if (!s || !d_xu || !d_xs || !d_ref) return fail(GATO_ERR_INVALID, "null argument");
+    GUARD(s);
     return solve_dispatch(s, d_xu, dt, d_xs, d_ref, (hipStream_t)stream);
 }
 
 extern "C" int gato_solve(GatoSolver* s, float* xu, float dt, const float* x_s, const float* ref, double* sqp_time_us)
 {
     if (!s || !xu || !x_s || !ref) return fail(GATO_ERR_INVALID, "null argument");
+    GUARD(s);
     const size_t nxu = (size_t)s->B * s->traj * sizeof(float);
     HIPCHK(hipMemcpy(s->d_xu_own, xu, nxu, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(s->d_xs_own, x_s, (size_t)s->B * s->nx * sizeof(float), hipMemcpyHostToDevice));
@@ -451,12 +535,21 @@ extern "C" int gato_solve(GatoSolver* s, float* xu, float dt, const float* x_s, 
 // ---- statistics -------------------------------------------------------------------------------------------------------
 static int sync_last(GatoSolver* s)
 {
-    HIPCHK(hipStreamSynchronize(s->last_stream));
+    // a solve enqueued on the caller's stream (gato_solve_device) may still be in flight: everything that reads or overwrites solver
+    // state from the host waits for it first
+    if (s->last_stream_valid) HIPCHK(hipStreamSynchronize(s->last_stream));
     return GATO_OK;
+}
+extern "C" int gato_synchronize(GatoSolver* s)
+{
+    if (!s) return fail(GATO_ERR_INVALID, "null solver");
+    GUARD(s);
+    return sync_last(s);
 }
 extern "C" int gato_get_counts(GatoSolver* s, uint32_t* iters_done, uint32_t* ls)
 {
     if (!s) return fail(GATO_ERR_INVALID, "null solver");
+    GUARD(s);
     int rc = sync_last(s);
     if (rc) return rc;
     Ctrl c;
@@ -467,120 +560,102 @@ extern "C" int gato_get_counts(GatoSolver* s, uint32_t* iters_done, uint32_t* ls
 }
 extern "C" int gato_get_sqp_iters(GatoSolver* s, int32_t* out)
 {
+    if (!s || !out) return fail(GATO_ERR_INVALID, "null argument");
     uint32_t it = 0;
     int rc = gato_get_counts(s, &it, nullptr);
     if (rc) return rc;
     for (int b = 0; b < s->B; b++) out[b] = (int32_t)it;  // every trajectory counts every executed iteration (bsqp.cuh:153-162)
     return GATO_OK;
 }
-extern "C" int gato_get_kkt_converged(GatoSolver* s, int32_t* out)
+// one device array of the last solve -> host (synchronises the solver's stream first)
+template<typename T> static int read_back(GatoSolver* s, T* out, const T* d_src, size_t count)
 {
     if (!s || !out) return fail(GATO_ERR_INVALID, "null argument");
+    GUARD(s);
     int rc = sync_last(s);
     if (rc) return rc;
-    HIPCHK(hipMemcpy(out, s->bf.converged, s->B * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (count) HIPCHK(hipMemcpy(out, d_src, count * sizeof(T), hipMemcpyDeviceToHost));
     return GATO_OK;
 }
-extern "C" int gato_get_final_merit(GatoSolver* s, float* out)
-{
-    if (!s || !out) return fail(GATO_ERR_INVALID, "null argument");
-    int rc = sync_last(s);
-    if (rc) return rc;
-    HIPCHK(hipMemcpy(out, s->bf.merit_cur, s->B * sizeof(float), hipMemcpyDeviceToHost));
-    return GATO_OK;
-}
-extern "C" int gato_get_initial_merit(GatoSolver* s, float* out)
-{
-    if (!s || !out) return fail(GATO_ERR_INVALID, "null argument");
-    int rc = sync_last(s);
-    if (rc) return rc;
-    HIPCHK(hipMemcpy(out, s->d_merit_init0, s->B * sizeof(float), hipMemcpyDeviceToHost));
-    return GATO_OK;
-}
+extern "C" int gato_get_kkt_converged(GatoSolver* s, int32_t* out) { return read_back(s, out, s ? s->bf.converged : nullptr, s ? s->B : 0); }
+extern "C" int gato_get_final_merit(GatoSolver* s, float* out) { return read_back(s, out, s ? s->bf.merit_cur : nullptr, s ? s->B : 0); }
+extern "C" int gato_get_initial_merit(GatoSolver* s, float* out) { return read_back(s, out, s ? s->d_merit_init0 : nullptr, s ? s->B : 0); }
 extern "C" int gato_get_pcg_iters(GatoSolver* s, int32_t* out)
 {
+    if (!s || !out) return fail(GATO_ERR_INVALID, "null argument");
     uint32_t it = 0;
     int rc = gato_get_counts(s, &it, nullptr);
     if (rc) return rc;
-    if (it) HIPCHK(hipMemcpy(out, s->bf.st_pcg_iters, (size_t)it * s->B * sizeof(int32_t), hipMemcpyDeviceToHost));
-    return GATO_OK;
+    return read_back(s, out, s->bf.st_pcg_iters, (size_t)it * s->B);
 }
 extern "C" int gato_get_ls_min_merit(GatoSolver* s, float* out)
 {
+    if (!s || !out) return fail(GATO_ERR_INVALID, "null argument");
     uint32_t ls = 0;
     int rc = gato_get_counts(s, nullptr, &ls);
     if (rc) return rc;
-    if (ls) HIPCHK(hipMemcpy(out, s->bf.st_min_merit, (size_t)ls * s->B * sizeof(float), hipMemcpyDeviceToHost));
-    return GATO_OK;
+    return read_back(s, out, s->bf.st_min_merit, (size_t)ls * s->B);
 }
 extern "C" int gato_get_ls_step_size(GatoSolver* s, float* out)
 {
+    if (!s || !out) return fail(GATO_ERR_INVALID, "null argument");
     uint32_t ls = 0;
     int rc = gato_get_counts(s, nullptr, &ls);
     if (rc) return rc;
-    if (ls) HIPCHK(hipMemcpy(out, s->bf.st_step, (size_t)ls * s->B * sizeof(float), hipMemcpyDeviceToHost));
-    return GATO_OK;
+    return read_back(s, out, s->bf.st_step, (size_t)ls * s->B);
 }
 
 // ---- setters (bsqp.cuh:63-89) -------------------------------------------------------------------------------------------
-extern "C" int gato_set_f_ext_batch(GatoSolver* s, const float* v)
+// host array -> per-trajectory device array, after the solve in flight (if any) is done with it
+static int write_param(GatoSolver* s, float* d_dst, const float* v, size_t count, float* d_default = nullptr, std::vector<float>* h_default = nullptr)
 {
     if (!s || !v) return fail(GATO_ERR_INVALID, "null argument");
-    HIPCHK(hipMemcpy(s->bf.f_ext, v, 6 * (size_t)s->B * sizeof(float), hipMemcpyHostToDevice));
+    GUARD(s);
+    int rc = sync_last(s);
+    if (rc) return rc;
+    if (d_default) {
+        h_default->assign(v, v + count);
+        HIPCHK(hipMemcpy(d_default, v, count * sizeof(float), hipMemcpyHostToDevice));
+    }
+    HIPCHK(hipMemcpy(d_dst, v, count * sizeof(float), hipMemcpyHostToDevice));
     return GATO_OK;
 }
+extern "C" int gato_set_f_ext_batch(GatoSolver* s, const float* v) { return write_param(s, s ? s->bf.f_ext : nullptr, v, s ? 6 * (size_t)s->B : 0); }
 extern "C" int gato_set_rho_penalty_batch(GatoSolver* s, const float* v, int as_default)
 {
-    if (!s || !v) return fail(GATO_ERR_INVALID, "null argument");
-    if (as_default) {
-        s->h_rho_init.assign(v, v + s->B);
-        HIPCHK(hipMemcpy(s->d_rho_init, v, s->B * sizeof(float), hipMemcpyHostToDevice));
-    }
-    HIPCHK(hipMemcpy(s->bf.rho, v, s->B * sizeof(float), hipMemcpyHostToDevice));
-    return GATO_OK;
+    if (!s) return fail(GATO_ERR_INVALID, "null solver");
+    return write_param(s, s->bf.rho, v, s->B, as_default ? s->d_rho_init : nullptr, &s->h_rho_init);
 }
 extern "C" int gato_set_drho_batch(GatoSolver* s, const float* v, int as_default)
 {
-    if (!s || !v) return fail(GATO_ERR_INVALID, "null argument");
-    if (as_default) {
-        s->h_drho_init.assign(v, v + s->B);
-        HIPCHK(hipMemcpy(s->d_drho_init, v, s->B * sizeof(float), hipMemcpyHostToDevice));
-    }
-    HIPCHK(hipMemcpy(s->bf.drho, v, s->B * sizeof(float), hipMemcpyHostToDevice));
-    return GATO_OK;
+    if (!s) return fail(GATO_ERR_INVALID, "null solver");
+    return write_param(s, s->bf.drho, v, s->B, as_default ? s->d_drho_init : nullptr, &s->h_drho_init);
 }
-extern "C" int gato_set_mu_batch(GatoSolver* s, const float* v)
-{
-    if (!s || !v) return fail(GATO_ERR_INVALID, "null argument");
-    HIPCHK(hipMemcpy(s->bf.mu, v, s->B * sizeof(float), hipMemcpyHostToDevice));
-    return GATO_OK;
-}
+extern "C" int gato_set_mu_batch(GatoSolver* s, const float* v) { return write_param(s, s ? s->bf.mu : nullptr, v, s ? s->B : 0); }
+extern "C" int gato_set_pcg_tol_batch(GatoSolver* s, const float* v) { return write_param(s, s ? s->bf.pcg_tol : nullptr, v, s ? s->B : 0); }
 extern "C" int gato_set_cost_weights_batch(GatoSolver* s, const float* w)
 {
     if (!s || !w) return fail(GATO_ERR_INVALID, "null argument");
-    int rc = sync_last(s);
-    if (rc) return rc;
     std::vector<float> p(8 * (size_t)s->B, 0.f);
     for (int b = 0; b < s->B; b++)
         for (int i = 0; i < 7; i++) p[8 * (size_t)b + i] = w[7 * (size_t)b + i];
-    HIPCHK(hipMemcpy(s->d_costw, p.data(), p.size() * sizeof(float), hipMemcpyHostToDevice));
-    return GATO_OK;
-}
-extern "C" int gato_set_pcg_tol_batch(GatoSolver* s, const float* v)
-{
-    if (!s || !v) return fail(GATO_ERR_INVALID, "null argument");
-    HIPCHK(hipMemcpy(s->bf.pcg_tol, v, s->B * sizeof(float), hipMemcpyHostToDevice));
-    return GATO_OK;
+    return write_param(s, s->d_costw, p.data(), p.size());
 }
 extern "C" int gato_reset_dual(GatoSolver* s)
 {
     if (!s) return fail(GATO_ERR_INVALID, "null solver");
+    GUARD(s);
+    int rc = sync_last(s);
+    if (rc) return rc;
     HIPCHK(hipMemset(s->bf.lambda, 0, (size_t)s->B * s->vecp * sizeof(float)));
     return GATO_OK;
 }
 extern "C" int gato_reset_rho(GatoSolver* s)
 {
     if (!s) return fail(GATO_ERR_INVALID, "null solver");
+    GUARD(s);
+    int rc = sync_last(s);
+    if (rc) return rc;
     HIPCHK(hipMemcpy(s->bf.rho, s->h_rho_init.data(), s->B * sizeof(float), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(s->bf.drho, s->h_drho_init.data(), s->B * sizeof(float), hipMemcpyHostToDevice));
     return GATO_OK;
@@ -588,6 +663,7 @@ extern "C" int gato_reset_rho(GatoSolver* s)
 extern "C" int gato_reset_async(GatoSolver* s, int dual, int rho, void* stream)
 {
     if (!s) return fail(GATO_ERR_INVALID, "null solver");
+    GUARD(s);
     hipStream_t st = (hipStream_t)stream;
     if (dual) HIPCHK(hipMemsetAsync(s->bf.lambda, 0, (size_t)s->B * s->vecp * sizeof(float), st));
     if (rho) {
@@ -599,6 +675,7 @@ extern "C" int gato_reset_async(GatoSolver* s, int dual, int rho, void* stream)
 extern "C" int gato_copy_final_merit_device(GatoSolver* s, float* d_out, void* stream)
 {
     if (!s || !d_out) return fail(GATO_ERR_INVALID, "null argument");
+    GUARD(s);
     HIPCHK(hipMemcpyAsync(d_out, s->bf.merit_cur, s->B * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return GATO_OK;
 }
@@ -610,23 +687,31 @@ extern "C" int gato_set_rho_adaptation(GatoSolver* s, int enabled)
 }
 
 // ---- sim_forward / ee_pos -----------------------------------------------------------------------------------------------
+// BSQP::sim_forward(T* d_xkp1_batch, T* d_xk, T* d_uk, T dt) (bsqp.cuh:91): device pointers, enqueued on `stream`, no synchronisation
+extern "C" int gato_sim_forward_device(GatoSolver* s, float* d_xkp1, const float* d_xk, const float* d_uk, float dt, void* stream)
+{
+    if (!s || !d_xkp1 || !d_xk || !d_uk) return fail(GATO_ERR_INVALID, "null argument");
+    GUARD(s);
+    hipStream_t st = (hipStream_t)stream;
+    if (s->plant == GATO_PLANT_INDY7)
+        hipLaunchKernelGGL((sim_forward_kernel<Indy7>), dim3(cdiv(s->B, 256)), dim3(256), 0, st, d_xkp1, d_xk, d_uk, s->bf.f_ext, s->B, dt);
+    else
+        hipLaunchKernelGGL((sim_forward_kernel<Iiwa14>), dim3(cdiv(s->B, 256)), dim3(256), 0, st, d_xkp1, d_xk, d_uk, s->bf.f_ext, s->B, dt);
+    HIPCHK(hipGetLastError());
+    return GATO_OK;
+}
+// PyBSQP::sim_forward (bindings.cu:180-194): host arrays through the staging buffers the solver owns (no per-call allocation)
 extern "C" int gato_sim_forward(GatoSolver* s, float* xkp1, const float* xk, const float* uk, float dt)
 {
     if (!s || !xkp1 || !xk || !uk) return fail(GATO_ERR_INVALID, "null argument");
-    float* d_in = s->d_xs_own;  // reuse: nx + nu floats fit in B*nx
-    HIPCHK(hipMemcpy(d_in, xk, s->nx * sizeof(float), hipMemcpyHostToDevice));
-    float* d_u = nullptr;
-    std::vector<float> tmp(uk, uk + s->nu);
-    HIPCHK(hipMalloc((void**)&d_u, s->nu * sizeof(float)));
-    HIPCHK(hipMemcpy(d_u, tmp.data(), s->nu * sizeof(float), hipMemcpyHostToDevice));
-    if (s->plant == GATO_PLANT_INDY7)
-        hipLaunchKernelGGL((sim_forward_kernel<Indy7>), dim3(cdiv(s->B, 256)), dim3(256), 0, nullptr, s->d_scratch_B, d_in, d_u, s->bf.f_ext, s->B, dt);
-    else
-        hipLaunchKernelGGL((sim_forward_kernel<Iiwa14>), dim3(cdiv(s->B, 256)), dim3(256), 0, nullptr, s->d_scratch_B, d_in, d_u, s->bf.f_ext, s->B, dt);
-    hipError_t e = hipDeviceSynchronize();
-    (void)hipFree(d_u);
-    if (e != hipSuccess) return fail(GATO_ERR_HIP, hipGetErrorString(e));
-    HIPCHK(hipMemcpy(xkp1, s->d_scratch_B, (size_t)s->B * s->nx * sizeof(float), hipMemcpyDeviceToHost));
+    GUARD(s);
+    int rc = sync_last(s);  // the wrenches may have been set behind a solve that still reads them
+    if (rc) return rc;
+    HIPCHK(hipMemcpy(s->d_sim_x, xk, s->nx * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(s->d_sim_u, uk, s->nu * sizeof(float), hipMemcpyHostToDevice));
+    rc = gato_sim_forward_device(s, s->d_sim_out, s->d_sim_x, s->d_sim_u, dt, nullptr);
+    if (rc) return rc;
+    HIPCHK(hipMemcpy(xkp1, s->d_sim_out, (size_t)s->B * s->nx * sizeof(float), hipMemcpyDeviceToHost));  // blocking on the null stream
     return GATO_OK;
 }
 
@@ -634,18 +719,21 @@ extern "C" int gato_ee_pos(GatoSolver* s, const float* q, int n, float* out)
 {
     if (!s || !q || !out || n < 0) return fail(GATO_ERR_INVALID, "bad argument");
     if (n == 0) return GATO_OK;
-    float *d_q = nullptr, *d_o = nullptr;
-    HIPCHK(hipMalloc((void**)&d_q, (size_t)n * s->nq * sizeof(float)));
-    if (hipMalloc((void**)&d_o, (size_t)n * 3 * sizeof(float)) != hipSuccess) { (void)hipFree(d_q); return fail(GATO_ERR_HIP, "hipMalloc"); }
-    hipError_t e = hipMemcpy(d_q, q, (size_t)n * s->nq * sizeof(float), hipMemcpyHostToDevice);
-    if (e == hipSuccess) {
-        if (s->plant == GATO_PLANT_INDY7) hipLaunchKernelGGL((ee_pos_kernel<Indy7>), dim3(cdiv(n, 256)), dim3(256), 0, nullptr, d_o, d_q, n);
-        else hipLaunchKernelGGL((ee_pos_kernel<Iiwa14>), dim3(cdiv(n, 256)), dim3(256), 0, nullptr, d_o, d_q, n);
-        e = hipMemcpy(out, d_o, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost);
+    GUARD(s);
+    if ((size_t)n > s->ee_cap) {  // staging grows to the largest request seen (the MPC loop asks for one configuration per step)
+        if (s->d_ee_q) (void)hipFree(s->d_ee_q);
+        if (s->d_ee_out) (void)hipFree(s->d_ee_out);
+        s->d_ee_q = s->d_ee_out = nullptr;
+        s->ee_cap = 0;
+        HIPCHK(hipMalloc((void**)&s->d_ee_q, (size_t)n * s->nq * sizeof(float)));
+        HIPCHK(hipMalloc((void**)&s->d_ee_out, (size_t)n * 3 * sizeof(float)));
+        s->ee_cap = (size_t)n;
     }
-    (void)hipFree(d_q);
-    (void)hipFree(d_o);
-    if (e != hipSuccess) return fail(GATO_ERR_HIP, hipGetErrorString(e));
+    HIPCHK(hipMemcpy(s->d_ee_q, q, (size_t)n * s->nq * sizeof(float), hipMemcpyHostToDevice));
+    if (s->plant == GATO_PLANT_INDY7) hipLaunchKernelGGL((ee_pos_kernel<Indy7>), dim3(cdiv(n, 256)), dim3(256), 0, nullptr, s->d_ee_out, s->d_ee_q, n);
+    else hipLaunchKernelGGL((ee_pos_kernel<Iiwa14>), dim3(cdiv(n, 256)), dim3(256), 0, nullptr, s->d_ee_out, s->d_ee_q, n);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(out, s->d_ee_out, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost));
     return GATO_OK;
 }
 
@@ -663,6 +751,7 @@ static float* find_buf(GatoSolver* s, const char* name, uint64_t* len)
         {"dz", s->bf.dz, (uint64_t)s->B * s->traj}, {"merit", s->bf.merit, (uint64_t)s->B * NUM_ALPHAS}, {"merit_cur", s->bf.merit_cur, (uint64_t)s->B},
         {"rho", s->bf.rho, (uint64_t)s->B}, {"drho", s->bf.drho, (uint64_t)s->B}, {"step", s->bf.step, (uint64_t)s->B},
         {"mu", s->bf.mu, (uint64_t)s->B}, {"pcg_tol", s->bf.pcg_tol, (uint64_t)s->B}, {"f_ext", s->bf.f_ext, (uint64_t)s->B * 6},
+        {"xu", s->d_xu_own, (uint64_t)s->B * s->traj},  // the solver's own copy (gato_solve / gato_debug_stage), not a caller's device buffer
     };
     for (const E& e : tab)
         if (!strcmp(e.n, name)) { *len = e.l; return e.p; }
@@ -671,6 +760,7 @@ static float* find_buf(GatoSolver* s, const char* name, uint64_t* len)
 extern "C" int gato_debug_read(GatoSolver* s, const char* name, float* out, uint64_t count, uint64_t* len)
 {
     if (!s || !name) return fail(GATO_ERR_INVALID, "null argument");
+    GUARD(s);
     uint64_t l = 0;
     float* p = find_buf(s, name, &l);
     if (!p) {
@@ -694,6 +784,7 @@ extern "C" int gato_debug_read(GatoSolver* s, const char* name, float* out, uint
 extern "C" int gato_debug_write(GatoSolver* s, const char* name, const float* in, uint64_t count)
 {
     if (!s || !name || !in) return fail(GATO_ERR_INVALID, "null argument");
+    GUARD(s);
     uint64_t l = 0;
     float* p = find_buf(s, name, &l);
     if (!p) {
@@ -734,12 +825,14 @@ template<class M> static int stage_impl(GatoSolver* s, int stage, float dt, floa
 extern "C" int gato_debug_stage(GatoSolver* s, int stage, float* xu, float dt, const float* x_s, const float* ref, float* out)
 {
     if (!s || !xu || !x_s || !ref) return fail(GATO_ERR_INVALID, "null argument");
+    GUARD(s);
     const size_t nxu = (size_t)s->B * s->traj * sizeof(float);
     HIPCHK(hipMemcpy(s->d_xu_own, xu, nxu, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(s->d_xs_own, x_s, (size_t)s->B * s->nx * sizeof(float), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(s->d_ref_own, ref, (size_t)s->B * 6 * s->N * sizeof(float), hipMemcpyHostToDevice));
     s->bf.xu = s->d_xu_own; s->bf.x_s = s->d_xs_own; s->bf.ref = s->d_ref_own;
     s->last_stream = nullptr;
+    s->last_stream_valid = true;
     int rc = s->plant == GATO_PLANT_INDY7 ? stage_impl<Indy7>(s, stage, dt, out) : stage_impl<Iiwa14>(s, stage, dt, out);
     if (rc) return rc;
     HIPCHK(hipMemcpy(xu, s->d_xu_own, nxu, hipMemcpyDeviceToHost));
@@ -755,6 +848,7 @@ extern "C" int gato_set_profiling(GatoSolver* s, int enabled)
 extern "C" int gato_get_stage_times_us(GatoSolver* s, double* out7)
 {
     if (!s || !out7) return fail(GATO_ERR_INVALID, "null argument");
+    GUARD(s);
     int rc = sync_last(s);
     if (rc) return rc;
     collect_profile(s);

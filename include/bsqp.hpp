@@ -6,6 +6,7 @@
 // Plant and horizon are template/ctor arguments here instead of -D defines: BSQP<float, 16> solver(GATO_PLANT_INDY7, 16, dt, ...).
 // If GATO_PLANT and KNOT_POINTS macros are defined (the reference's build convention) they are the defaults.
 #pragma once
+#include <chrono>
 #include <cstdint>
 #include <stdexcept>
 #include <string>
@@ -87,12 +88,19 @@ class BSQP {
     void set_rho_adaptation(bool enabled) { chk(gato_set_rho_adaptation(s_, enabled)); }
     void copy_final_merit_to_host(T* h_out) { chk(gato_get_final_merit(s_, h_out)); }
     void copy_initial_merit0_to_host(T* h_out) { chk(gato_get_initial_merit(s_, h_out)); }
+    // bsqp.cuh:91 -- one integrator step of the shared (x_k, u_k) under the B stored wrenches, device pointers, default stream
+    void sim_forward(T* d_xkp1_batch, T* d_xk, T* d_uk, T dt) { chk(gato_sim_forward_device(s_, d_xkp1_batch, d_xk, d_uk, dt, nullptr)); }
 
     // device-pointer solve, blocking like the reference's (its loop synchronises on the pageable D2H copies, bsqp.cuh:137,184)
     SQPStats<T, BatchSize> solve(T* d_xu_traj_batch, ProblemInputs<T, BatchSize> inputs)
     {
+        // solve_time_us: host wall clock around the device-synchronised SQP loop, like bsqp.cuh:109,185,190
+        const auto t0 = std::chrono::high_resolution_clock::now();
         chk(gato_solve_device(s_, d_xu_traj_batch, inputs.timestep, inputs.d_x_s_batch, inputs.d_reference_traj_batch, nullptr));
+        chk(gato_synchronize(s_));
+        const auto t1 = std::chrono::high_resolution_clock::now();
         SQPStats<T, BatchSize> st;
+        st.solve_time_us = std::chrono::duration<double, std::micro>(t1 - t0).count();
         uint32_t iters = 0, ls = 0;
         chk(gato_get_counts(s_, &iters, &ls));
         chk(gato_get_sqp_iters(s_, st.sqp_iterations.data()));
@@ -115,8 +123,6 @@ class BSQP {
             }
             st.line_search_stats.push_back(l);
         }
-        double t[7];
-        if (gato_get_stage_times_us(s_, t) == GATO_OK) st.solve_time_us = t[6];
         return st;
     }
 

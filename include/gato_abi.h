@@ -68,6 +68,9 @@ int gato_solve(GatoSolver* s, float* xu, float timestep, const float* x_s, const
  * synchronisation: the caller synchronises the stream before reading d_xu or calling the gato_get_* functions. */
 int gato_solve_device(GatoSolver* s, float* d_xu, float timestep, const float* d_x_s, const float* d_ref, void* stream);
 
+/* Waits for the solve in flight on the stream of the last gato_solve_device call (no-op when there is none). */
+int gato_synchronize(GatoSolver* s);
+
 /* Stream-ordered variants for callers that keep everything on one HIP stream (bench.py, the multi-GPU layer): the resets of
  * bsqp.cuh:81-87 as device-side copies enqueued on `stream`, and the final merits copied device-to-device into d_out [B]. */
 int gato_reset_async(GatoSolver* s, int reset_dual, int reset_rho, void* stream);
@@ -103,13 +106,16 @@ int gato_set_rho_adaptation(GatoSolver* s, int enabled);
 /* BSQP::sim_forward / PyBSQP::sim_forward (bsqp.cuh:91, bindings.cu:180-194): one integrator step of the SHARED (xk, uk) under the
  * B stored wrench hypotheses; xkp1 is [B][nx] on the host. */
 int gato_sim_forward(GatoSolver* s, float* xkp1, const float* xk, const float* uk, float dt);
+/* BSQP::sim_forward(T* d_xkp1_batch, T* d_xk, T* d_uk, T dt) itself (bsqp.cuh:91, kernel sim.cuh:14-49): device pointers
+ * (d_xkp1 [B][nx], d_xk [nx], d_uk [nu]), enqueued on `stream` without a host synchronisation. */
+int gato_sim_forward_device(GatoSolver* s, float* d_xkp1, const float* d_xk, const float* d_uk, float dt, void* stream);
 
 /* End-effector positions [n][3] of n joint configurations [n][nq] (host arrays): what interface.BSQP.ee_pos obtains from
  * pinocchio in the reference (python/bsqp/interface.py:212-214), computed with the solver's own kinematics. */
 int gato_ee_pos(GatoSolver* s, const float* q, int n, float* out);
 
-/* Debug / test access to a device buffer by name ("xu" is not owned and not available):
- * "D","Qq","Qd","Rd","q","r","c","Qqi","Qdi","Rdi","S","Pinv","gamma","lambda","dz","merit","merit_cur","rho","drho", "step".
+/* Debug / test access to a device buffer by name ("xu" = the solver's own copy used by gato_solve / gato_debug_stage):
+ * "xu","D","Qq","Qd","Rd","q","r","c","Qqi","Qdi","Rdi","S","Pinv","gamma","lambda","dz","merit","merit_cur","rho","drho", "step".
  * Copies `count` floats to `out`; returns the buffer length in floats through *len when out == NULL. */
 int gato_debug_read(GatoSolver* s, const char* name, float* out, uint64_t count, uint64_t* len);
 int gato_debug_write(GatoSolver* s, const char* name, const float* in, uint64_t count);

@@ -30,6 +30,7 @@
 #define RHO_FACTOR 1.2f        /* gato/settings.h:20 */
 #define RHO_MIN 1e-8f          /* gato/settings.h:21 */
 #define RHO_MAX 10.0f          /* gato/settings.h:22 */
+#define RHO_INIT 1e-3f         /* gato/settings.h:18 */
 #define GRAVITY 9.81f          /* gato/dynamics/indy7/indy7_plant.cuh:25-28 */
 
 typedef struct {
@@ -886,6 +887,7 @@ static void line_search_one(Orc* o, int b, float* xu)
         o->rho[b] = fminf(o->rho[b], RHO_MAX);
     }
     if (!success) {
+        if (o->rho[b] > RHO_MAX) o->rho[b] = RHO_INIT; /* line_search.cuh:77-79: live only with adaptation off and rho_batch > RHO_MAX */
         o->step[b] = -1.f;
     } else {
         float step = (float)(1.0 / (double)(1 << idx));

@@ -15,11 +15,17 @@ PLANTS = {"indy7": 0, "iiwa14": 1}
 NQ = {"indy7": 6, "iiwa14": 7}
 
 
-class OrcParams(C.Structure):
-    _fields_ = [("dt", C.c_float), ("max_sqp_iters", C.c_uint32), ("kkt_tol", C.c_float), ("max_pcg_iters", C.c_uint32),
-                ("pcg_tol", C.c_float), ("solve_ratio", C.c_float), ("mu", C.c_float), ("q_cost", C.c_float), ("qd_cost", C.c_float),
-                ("u_cost", C.c_float), ("N_cost", C.c_float), ("q_lim_cost", C.c_float), ("vel_lim_cost", C.c_float),
-                ("ctrl_lim_cost", C.c_float), ("rho", C.c_float)]
+def _params_struct(ft):
+    class P(C.Structure):
+        _fields_ = [("dt", ft), ("max_sqp_iters", C.c_uint32), ("kkt_tol", ft), ("max_pcg_iters", C.c_uint32), ("pcg_tol", ft),
+                    ("solve_ratio", ft), ("mu", ft), ("q_cost", ft), ("qd_cost", ft), ("u_cost", ft), ("N_cost", ft), ("q_lim_cost", ft),
+                    ("vel_lim_cost", ft), ("ctrl_lim_cost", ft), ("rho", ft)]
+    return P
+
+
+OrcParams = _params_struct(C.c_float)
+OrcParams64 = _params_struct(C.c_double)   # the -Dfloat=double build of the same source (oracle/Makefile: libgato_oracle_f64.so)
+LIB_PATH_F64 = os.path.join(HERE, "libgato_oracle_f64.so")
 
 
 def build(force=False):
@@ -32,18 +38,25 @@ def build(force=False):
 _lib = None
 
 
-def lib():
-    global _lib
-    if _lib is None:
-        if not os.path.exists(LIB_PATH):
+_libs = {}
+
+
+def lib(f64=False):
+    """The fp32 oracle (default) or the float64 build of the same source (sensitivity studies: tests/test_oracle_sensitivity.py)."""
+    key = bool(f64)
+    if key not in _libs:
+        path = LIB_PATH_F64 if key else LIB_PATH
+        if not os.path.exists(path):
             build()
-        L = C.CDLL(LIB_PATH)
-        fp = C.POINTER(C.c_float)
+        ft = C.c_double if key else C.c_float
+        PT = OrcParams64 if key else OrcParams
+        L = C.CDLL(path)
+        fp = C.POINTER(ft)
         L.orc_create.restype = C.c_void_p
-        L.orc_create.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(OrcParams)]
+        L.orc_create.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(PT)]
         L.orc_destroy.argtypes = [C.c_void_p]
         L.orc_solve.restype = C.c_uint32
-        L.orc_solve.argtypes = [C.c_void_p, fp, C.c_float, fp, fp]
+        L.orc_solve.argtypes = [C.c_void_p, fp, ft, fp, fp]
         L.orc_buf.restype = fp
         L.orc_buf.argtypes = [C.c_void_p, C.c_char_p]
         L.orc_ibuf.restype = C.POINTER(C.c_int32)
@@ -56,10 +69,10 @@ def lib():
             getattr(L, name).argtypes = [C.c_void_p]
         L.orc_set_rho_adaptation.argtypes = [C.c_void_p, C.c_int]
         L.orc_set_threads.argtypes = [C.c_void_p, C.c_int]
-        L.orc_setup_kkt.argtypes = [C.c_void_p, fp, fp, fp, C.c_float]
-        L.orc_merit.argtypes = [C.c_void_p, C.c_int, fp, fp, fp, fp, C.c_float, C.c_int]
+        L.orc_setup_kkt.argtypes = [C.c_void_p, fp, fp, fp, ft]
+        L.orc_merit.argtypes = [C.c_void_p, C.c_int, fp, fp, fp, fp, ft, C.c_int]
         L.orc_line_search.argtypes = [C.c_void_p, fp]
-        L.orc_sim_forward.argtypes = [C.c_void_p, fp, fp, fp, C.c_float]
+        L.orc_sim_forward.argtypes = [C.c_void_p, fp, fp, fp, ft]
         L.orc_iters_done.restype = C.c_uint32
         L.orc_iters_done.argtypes = [C.c_void_p]
         L.orc_ls_done.restype = C.c_uint32
@@ -70,13 +83,15 @@ def lib():
         L.orc_minv.argtypes = [C.c_int, fp, fp]
         L.orc_ee.argtypes = [C.c_int, fp, fp, fp]
         L.orc_gj_inverse.argtypes = [C.c_int, fp, fp, C.c_int]
-        _lib = L
-    return _lib
+        L._ft, L._np, L._PT = ft, (np.float64 if key else np.float32), PT
+        _libs[key] = L
+    return _libs[key]
 
 
-def _f(a):
-    a = np.ascontiguousarray(a, dtype=np.float32)
-    return a, a.ctypes.data_as(C.POINTER(C.c_float))
+def _f(a, L=None):
+    dt = np.float32 if L is None else L._np
+    a = np.ascontiguousarray(a, dtype=dt)
+    return a, a.ctypes.data_as(C.POINTER(C.c_float if L is None else L._ft))
 
 
 PARAM_ORDER = ["dt", "max_sqp_iters", "kkt_tol", "max_pcg_iters", "pcg_tol", "solve_ratio", "mu", "q_cost", "qd_cost", "u_cost", "N_cost",
@@ -87,50 +102,52 @@ class OracleSolver:
     """Mirror of the `BSQP_{B}_float` class surface (python/bindings.cu:224-237) on the CPU oracle, plus stage access."""
 
     def __init__(self, plant, N, B, dt=0.01, max_sqp_iters=5, kkt_tol=1e-4, max_pcg_iters=100, pcg_tol=1e-5, solve_ratio=1.0, mu=10.0,
-                 q_cost=1.0, qd_cost=1e-3, u_cost=1e-6, N_cost=50.0, q_lim_cost=1e-3, vel_lim_cost=0.0, ctrl_lim_cost=0.0, rho=1e-3, threads=1):
+                 q_cost=1.0, qd_cost=1e-3, u_cost=1e-6, N_cost=50.0, q_lim_cost=1e-3, vel_lim_cost=0.0, ctrl_lim_cost=0.0, rho=1e-3, threads=1, f64=False):
         self.plant, self.N, self.B = plant, N, B
         self.nq = NQ[plant]
         self.nx, self.nu = 2 * self.nq, self.nq
         self.traj = (self.nx + self.nu) * N - self.nu
         self.max_sqp_iters = max_sqp_iters
-        self.p = OrcParams(dt, max_sqp_iters, kkt_tol, max_pcg_iters, pcg_tol, solve_ratio, mu, q_cost, qd_cost, u_cost, N_cost, q_lim_cost,
+        self.L = lib(f64)
+        self.dtype = self.L._np
+        self.p = self.L._PT(dt, max_sqp_iters, kkt_tol, max_pcg_iters, pcg_tol, solve_ratio, mu, q_cost, qd_cost, u_cost, N_cost, q_lim_cost,
                            vel_lim_cost, ctrl_lim_cost, rho)
-        self.h = lib().orc_create(PLANTS[plant], N, B, C.byref(self.p))
-        lib().orc_set_threads(self.h, threads)
+        self.h = self.L.orc_create(PLANTS[plant], N, B, C.byref(self.p))
+        self.L.orc_set_threads(self.h, threads)
 
     def __del__(self):
         if getattr(self, "h", None):
-            lib().orc_destroy(self.h)
+            self.L.orc_destroy(self.h)
             self.h = None
 
     # ---- setters ----
     def set_f_ext_batch(self, f):
-        a, p = _f(np.asarray(f).reshape(self.B, 6)); lib().orc_set_f_ext(self.h, p)
+        a, p = _f(np.asarray(f).reshape(self.B, 6), self.L); self.L.orc_set_f_ext(self.h, p)
 
     def set_rho_penalty_batch(self, v, set_as_reset_default=True):
-        a, p = _f(v); lib().orc_set_rho(self.h, p, int(set_as_reset_default))
+        a, p = _f(v, self.L); self.L.orc_set_rho(self.h, p, int(set_as_reset_default))
 
     def set_drho_batch(self, v, set_as_reset_default=True):
-        a, p = _f(v); lib().orc_set_drho(self.h, p, int(set_as_reset_default))
+        a, p = _f(v, self.L); self.L.orc_set_drho(self.h, p, int(set_as_reset_default))
 
     def set_cost_weights_batch(self, w):
         """w[B,7] = q, qd, u, N, q_lim, vel_lim, ctrl_lim cost weights per trajectory"""
-        a, p = _f(w); assert a.size == 7 * self.B; lib().orc_set_cost_weights(self.h, p)
+        a, p = _f(w, self.L); assert a.size == 7 * self.B; self.L.orc_set_cost_weights(self.h, p)
 
     def set_mu_batch(self, v):
-        a, p = _f(v); lib().orc_set_mu(self.h, p)
+        a, p = _f(v, self.L); self.L.orc_set_mu(self.h, p)
 
     def set_pcg_tol_batch(self, v):
-        a, p = _f(v); lib().orc_set_pcg_tol(self.h, p)
+        a, p = _f(v, self.L); self.L.orc_set_pcg_tol(self.h, p)
 
     def reset_dual(self):
-        lib().orc_reset_dual(self.h)
+        self.L.orc_reset_dual(self.h)
 
     def reset_rho(self):
-        lib().orc_reset_rho(self.h)
+        self.L.orc_reset_rho(self.h)
 
     def set_rho_adaptation(self, e):
-        lib().orc_set_rho_adaptation(self.h, int(bool(e)))
+        self.L.orc_set_rho_adaptation(self.h, int(bool(e)))
 
     # ---- stage access ----
     SHAPES = {"Q": ("N", "nx", "nx"), "A": ("N", "nx", "nx"), "Qinv": ("N", "nx", "nx"), "R": ("N", "nu", "nu"), "Rinv": ("N", "nu", "nu"),
@@ -144,52 +161,52 @@ class OracleSolver:
     def buf(self, name):
         """Copy of a stage buffer as [B, ...]; matrices keep the reference's in-memory order (col-major blocks, row-major S/Pinv rows)."""
         shape = (self.B,) + tuple(self._dim(d) for d in self.SHAPES[name])
-        ptr = lib().orc_buf(self.h, name.encode())
+        ptr = self.L.orc_buf(self.h, name.encode())
         n = int(np.prod(shape))
         return np.ctypeslib.as_array(ptr, shape=(n,)).reshape(shape).copy()
 
     def ibuf(self, name, shape):
-        ptr = lib().orc_ibuf(self.h, name.encode())
+        ptr = self.L.orc_ibuf(self.h, name.encode())
         return np.ctypeslib.as_array(ptr, shape=(int(np.prod(shape)),)).reshape(shape).copy()
 
     def set_lambda(self, lam):
-        ptr = lib().orc_buf(self.h, b"lambda")
-        np.ctypeslib.as_array(ptr, shape=(self.B * (self.N + 2) * self.nx,))[:] = np.asarray(lam, np.float32).reshape(-1)
+        ptr = self.L.orc_buf(self.h, b"lambda")
+        np.ctypeslib.as_array(ptr, shape=(self.B * (self.N + 2) * self.nx,))[:] = np.asarray(lam, self.dtype).reshape(-1)
 
     def set_dz(self, dz):
-        ptr = lib().orc_buf(self.h, b"dz")
-        np.ctypeslib.as_array(ptr, shape=(self.B * self.traj,))[:] = np.asarray(dz, np.float32).reshape(-1)
+        ptr = self.L.orc_buf(self.h, b"dz")
+        np.ctypeslib.as_array(ptr, shape=(self.B * self.traj,))[:] = np.asarray(dz, self.dtype).reshape(-1)
 
     def setup_kkt(self, xu, x_s, ref, dt):
-        (_, a), (_, b), (_, c) = _f(xu), _f(x_s), _f(ref)
-        lib().orc_setup_kkt(self.h, a, b, c, dt)
+        (_, a), (_, b), (_, c) = _f(xu, self.L), _f(x_s, self.L), _f(ref, self.L)
+        self.L.orc_setup_kkt(self.h, a, b, c, dt)
 
     def form_schur(self):
-        lib().orc_form_schur(self.h)
+        self.L.orc_form_schur(self.h)
 
     def pcg(self):
-        lib().orc_pcg(self.h)
+        self.L.orc_pcg(self.h)
 
     def compute_dz(self):
-        lib().orc_compute_dz(self.h)
+        self.L.orc_compute_dz(self.h)
 
     def merit(self, xu, x_s, ref, dt, num_alphas=8, zero_dz=False):
-        out = np.zeros((self.B, num_alphas), np.float32)
-        (_, a), (_, b), (_, c) = _f(xu), _f(x_s), _f(ref)
-        lib().orc_merit(self.h, num_alphas, out.ctypes.data_as(C.POINTER(C.c_float)), a, b, c, dt, int(zero_dz))
+        out = np.zeros((self.B, num_alphas), self.dtype)
+        (_, a), (_, b), (_, c) = _f(xu, self.L), _f(x_s, self.L), _f(ref, self.L)
+        self.L.orc_merit(self.h, num_alphas, out.ctypes.data_as(C.POINTER(self.L._ft)), a, b, c, dt, int(zero_dz))
         return out
 
     # ---- solve ----
     def solve(self, xu, dt, x_s, ref):
         """Same result dict as PyBSQP::solve (python/bindings.cu:96-145); sqp_time_us is this CPU's wall time."""
         import time
-        xu = np.array(xu, dtype=np.float32, order="C").reshape(self.B, self.traj)
-        xs, pxs = _f(np.asarray(x_s).reshape(self.B, self.nx))
-        rf, prf = _f(np.asarray(ref).reshape(self.B, 6 * self.N))
+        xu = np.array(xu, dtype=self.dtype, order="C").reshape(self.B, self.traj)
+        xs, pxs = _f(np.asarray(x_s).reshape(self.B, self.nx), self.L)
+        rf, prf = _f(np.asarray(ref).reshape(self.B, 6 * self.N), self.L)
         t0 = time.perf_counter()
-        iters = lib().orc_solve(self.h, xu.ctypes.data_as(C.POINTER(C.c_float)), dt, pxs, prf)
+        iters = self.L.orc_solve(self.h, xu.ctypes.data_as(C.POINTER(self.L._ft)), dt, pxs, prf)
         t1 = time.perf_counter()
-        ls = lib().orc_ls_done(self.h)
+        ls = self.L.orc_ls_done(self.h)
         B = self.B
         mi = max(self.max_sqp_iters, 1)
         return {
@@ -200,18 +217,18 @@ class OracleSolver:
             "final_merit": self.buf("merit_cur"),
             "initial_merit": self.buf("merit_init0"),
             "ls_num_iters": int(ls),
-            "pcg_times_us": np.zeros(ls, np.float32),
+            "pcg_times_us": np.zeros(ls, self.dtype),
             "pcg_iters": self.ibuf("st_pcg_iters", (mi, B))[:ls],
-            "ls_min_merit": np.ctypeslib.as_array(lib().orc_buf(self.h, b"st_min_merit"), shape=(mi * B,)).reshape(mi, B)[:ls].copy(),
-            "ls_step_size": np.ctypeslib.as_array(lib().orc_buf(self.h, b"st_step"), shape=(mi * B,)).reshape(mi, B)[:ls].copy(),
+            "ls_min_merit": np.ctypeslib.as_array(self.L.orc_buf(self.h, b"st_min_merit"), shape=(mi * B,)).reshape(mi, B)[:ls].copy(),
+            "ls_step_size": np.ctypeslib.as_array(self.L.orc_buf(self.h, b"st_step"), shape=(mi * B,)).reshape(mi, B)[:ls].copy(),
             "iters_done": int(iters),
             "pcg_iters_all": self.ibuf("st_pcg_iters", (mi, B))[:iters],
         }
 
     def sim_forward(self, xk, uk, dt):
-        out = np.zeros((self.B, self.nx), np.float32)
-        (_, a), (_, b) = _f(xk), _f(uk)
-        lib().orc_sim_forward(self.h, out.ctypes.data_as(C.POINTER(C.c_float)), a, b, dt)
+        out = np.zeros((self.B, self.nx), self.dtype)
+        (_, a), (_, b) = _f(xk, self.L), _f(uk, self.L)
+        self.L.orc_sim_forward(self.h, out.ctypes.data_as(C.POINTER(self.L._ft)), a, b, dt)
         return out
 
 

@@ -26,15 +26,23 @@ def _worker(rank, world, port, N, B, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from gato_amd.bsqp.config import DEFAULT_SOLVER_PARAMS
     from gato_amd.bsqp.workloads import fig8_problem
-    from gato_amd.sharding import best_trajectory, gather_results, shard_bounds
+    import torch
+    from gato_amd.sharding import PackedResults, check_sharded_params, gather_results, shard_bounds
     from oracle.oracle import OracleSolver
     lo, hi = shard_bounds(B, world, rank)
     pr = fig8_problem("indy7", N, hi - lo, batch_offset=lo)
     p = dict(DEFAULT_SOLVER_PARAMS, max_sqp_iters=2)
+    check_sharded_params(p["solve_ratio"], world)
     s = OracleSolver("indy7", N, hi - lo, dt=0.01, **p)
     out = s.solve(pr["xu"], 0.01, pr["x_s"], pr["ref"])
-    g = gather_results({"XU": out["XU"], "final_merit": out["final_merit"], "sqp_iters": out["sqp_iters"]})
-    best = best_trajectory(out["final_merit"], rank)
+    # the per-solve data path of bench.py: one packed buffer per rank, ONE collective
+    pk = PackedResults(hi - lo, out["XU"].shape[1], world)
+    pk.xu.copy_(torch.from_numpy(out["XU"]))
+    pk.merit.copy_(torch.from_numpy(out["final_merit"]))
+    pk.all_gather()
+    g = {"XU": pk.global_xu().numpy().copy(), "final_merit": pk.global_merit().numpy().copy()}
+    g.update(gather_results({"sqp_iters": out["sqp_iters"]}))   # statistics go through the generic gather
+    best = pk.best()
     dist.barrier()
     if rank == 0:
         q.put((g, best))
@@ -61,12 +69,16 @@ def test_sharded_solve_equals_unsharded():
     ref = s.solve(pr["xu"], 0.01, pr["x_s"], pr["ref"])
     np.testing.assert_array_equal(g["XU"], ref["XU"])
     np.testing.assert_array_equal(g["final_merit"], ref["final_merit"])
-    assert g["XU"].shape == (B, 18 * N - 6)
+    assert g["XU"].shape == (B, 18 * N - 6) and np.all(g["sqp_iters"] == ref["sqp_iters"])
     assert best[1] == int(np.argmin(ref["final_merit"])) and abs(best[0] - float(ref["final_merit"].min())) < 1e-6
 
 
 def test_shard_bounds():
-    from gato_amd.sharding import shard_bounds
+    from gato_amd.sharding import check_sharded_params, shard_bounds
     assert shard_bounds(8192, 8, 3) == (3072, 4096)
     with pytest.raises(ValueError):
         shard_bounds(10, 4, 0)
+    check_sharded_params(1.0, 8)
+    check_sharded_params(0.5, 1)          # a single rank counts over the whole batch: fine
+    with pytest.raises(ValueError):
+        check_sharded_params(0.5, 2)      # the solved count couples the shards (bsqp.cuh:165): refused, not approximated

@@ -5,8 +5,13 @@ tolerance"):
   stage outputs from identical inputs      rel <= 1e-5  (dynamics, cost blocks, dz, merit)      [measured ~1e-6]
   Schur blocks / Gauss-Jordan inverses     rel <= 1e-4  (no pivoting amplifies rounding)        [measured ~3e-6]
   lambda from PCG                          rel <= 1e-3  (stops at a residual tolerance), iteration counts within +-1
-  full solves                              line-search steps identical, XU and merits rel <= 1e-3 over 3 iterations; with a tight
-                                           PCG tolerance the iterates agree to 1e-4 rel after one iteration
+  one SQP iteration, PCG at its floor      every trajectory: XU rel <= 1e-4 (iiwa14 3e-4), identical steps
+  three SQP iterations, PCG at its floor   every trajectory: identical steps, error against the FLOAT64 build of the oracle no larger than
+                                           max(2e-4, 4 x the fp32 oracle's own error against it) -- fp32 itself is 2e-4 (1 iteration) to
+                                           2e-3 (3 iterations) away from float64 on this problem (tools/sensitivity.py), so
+                                           a fixed 1e-4 over several iterations is below what ANY fp32 implementation can promise
+  ten SQP iterations, teacher-forced       every iteration restarted from the ORACLE's state (xu, lambda, rho, drho): dz, the 8 merits,
+                                           the step, rho and the new iterate of every trajectory at stage tolerances (no chaos, no subset)
 "rel" = max|a-b| / max(1, max|b|) per buffer.
 """
 import glob
@@ -23,6 +28,8 @@ from gato_amd.bsqp.workloads import fig8_problem  # noqa: E402
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 DT = 0.01
+GOLDEN_3IT_TOL = 2e-2
+TIGHT = dict(pcg_tol=1e-9, max_pcg_iters=1000)   # PCG exits on its absolute floor (pcg.cuh:96-141), not on the iteration cap
 
 
 def rel(a, b):
@@ -143,28 +150,131 @@ def test_against_committed_golden(path):
     # first iteration: identical inputs -> identical decisions
     np.testing.assert_array_equal(out["ls_step_size"][0], g["out_ls_step_size"][0])
     assert np.abs(out["pcg_iters"][0].astype(int) - g["out_pcg_iters"][0]).max() <= 1
-    # later iterations: PCG stops at a RELATIVE residual of 1e-4, so lambda (and dz) carry ~1e-2 of slack and a last-bit difference in
-    # P^-1 moves an iterate by 1e-3..1e-2 after three steps (measured between two builds of this library); the reference itself is not
-    # run-to-run reproducible at this level (float atomics, SURVEY.md 7 hard part 3).  Trajectories whose discrete decisions agree must agree:
-    same = np.all(out["ls_step_size"] == g["out_ls_step_size"], axis=0)
-    assert same.mean() >= 0.5
-    assert np.median(traj_err(out["XU"], g["out_XU"])[same]) < 5e-3
-    assert np.median(np.abs(out["final_merit"] - g["out_final_merit"])[same] / g["out_final_merit"][same]) < 2e-2
+    # later iterations of a free-running solve are covered, without chaos, by test_teacher_forced_iterations; here every trajectory of
+    # the (tiny) fixture must still land near the fixture's result -- fp32 sensitivity after 3 iterations is ~1e-3
+    assert traj_err(out["XU"], g["out_XU"]).max() < GOLDEN_3IT_TOL, traj_err(out["XU"], g["out_XU"])
 
 
-@pytest.mark.parametrize("plant,N,B", [("indy7", 32, 8), ("iiwa14", 32, 4)])
+def _report(name, **kw):
+    """measured numbers of a parity test -> gpurun_out/parity_measured.jsonl (documentation for DESIGN.md section 3, never an input)"""
+    try:
+        d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "parity_measured.jsonl"), "a") as f:
+            f.write(json.dumps(dict(test=name, **{k: (float(v) if np.isscalar(v) else v) for k, v in kw.items()})) + "\n")
+    except OSError:
+        pass
+
+
+@pytest.mark.parametrize("plant,N,B", [("indy7", 32, 8), ("iiwa14", 32, 4), ("iiwa14", 64, 4), ("iiwa14", 128, 4)])
 def test_iterate_parity_tight_pcg(plant, N, B):
-    """One SQP iteration with PCG run to its floor: iterates within 1e-4 rel (the north-star's bar), same step, same merit."""
-    nat, orc, pr = make(plant, N, B, 0.0, max_sqp_iters=1, pcg_tol=1e-9, max_pcg_iters=1000)
+    """One SQP iteration with PCG run to its floor: every trajectory's iterate within 1e-4 rel (the north-star's bar), same step."""
+    nat, orc, pr = make(plant, N, B, 0.0, max_sqp_iters=1, **TIGHT)
     rg = nat.solve(pr["xu"], DT, pr["x_s"], pr["ref"])
     ro = orc.solve(pr["xu"], DT, pr["x_s"], pr["ref"])
     np.testing.assert_array_equal(rg["ls_step_size"], ro["ls_step_size"])
-    # indy7 meets the north-star's 1e-4; iiwa14's Schur system is worse conditioned (measured 1.1e-4 between two fp32 summation orders)
-    assert rel(rg["XU"], ro["XU"]) < (1e-4 if plant == "indy7" else 3e-4)
+    e = traj_err(rg["XU"], ro["XU"])
+    _report("tight_1it", plant=plant, N=N, xu=e.max(), merit=relscale(rg["final_merit"], ro["final_merit"]))
+    # indy7 meets the north-star's 1e-4; iiwa14's Schur system is worse conditioned (1.1e-4 between two fp32 summation orders; the fp32
+    # oracle itself is 2e-4 .. 3e-4 from its float64 build here)
+    assert e.max() < (1e-4 if plant == "indy7" else 3e-4), e
     # the merit amplifies iterate differences (mu * |defect|_1 goes through M^-1 ~ 1e3 on the last joints): 1e-4 in XU is ~1e-2 here
     assert relscale(rg["final_merit"], ro["final_merit"]) < 2e-2
     assert relscale(rg["ls_min_merit"], ro["ls_min_merit"]) < 2e-2
     assert relscale(rg["initial_merit"], ro["initial_merit"]) < 1e-5
+
+
+@pytest.mark.parametrize("plant,N,B", [("indy7", 32, 16), ("iiwa14", 32, 8), ("iiwa14", 64, 4), ("iiwa14", 128, 4)])
+def test_three_iterations_against_float64(plant, N, B):
+    """Three free-running SQP iterations (rho adaptation on, lambda warm-started from iteration to iteration), PCG at its floor.
+    The arbiter is the FLOAT64 build of the oracle: every trajectory of the HIP path must be as close to it as the fp32 oracle is
+    (factor 4 for the different summation orders, floor 2e-4 = the one-iteration fp32 gap), with the oracle's steps."""
+    from oracle.oracle import OracleSolver
+    nat, o32, pr = make(plant, N, B, 0.0, max_sqp_iters=3, **TIGHT)
+    o64 = OracleSolver(plant, N, B, dt=DT, f64=True, **dict(DEFAULT_SOLVER_PARAMS, max_sqp_iters=3, **TIGHT))
+    rg = nat.solve(pr["xu"], DT, pr["x_s"], pr["ref"])
+    r32 = o32.solve(pr["xu"], DT, pr["x_s"], pr["ref"])
+    r64 = o64.solve(pr["xu"], DT, pr["x_s"], pr["ref"])
+    clear = np.all(r32["ls_step_size"] == r64["ls_step_size"], axis=0)      # decisions that do not hinge on fp32 rounding
+    assert clear.all(), "the fp32 oracle and its float64 build disagree on a step: pick another seed for this test"
+    np.testing.assert_array_equal(rg["ls_step_size"], r32["ls_step_size"])
+    eg, eo = traj_err(rg["XU"], r64["XU"]), traj_err(r32["XU"], r64["XU"])
+    _report("free_3it", plant=plant, N=N, gpu_vs_f64=eg.max(), o32_vs_f64=eo.max(), gpu_vs_o32=traj_err(rg["XU"], r32["XU"]).max(),
+            worst_ratio=(eg / np.maximum(eo, 5e-5)).max())
+    assert np.all(eg <= np.maximum(2e-4, 4.0 * eo)), (eg, eo)
+    mg = np.abs(rg["final_merit"] - r64["final_merit"]) / np.maximum(1.0, np.abs(r64["final_merit"]))
+    mo = np.abs(r32["final_merit"] - r64["final_merit"]) / np.maximum(1.0, np.abs(r64["final_merit"]))
+    assert np.all(mg <= np.maximum(2e-3, 4.0 * mo)), (mg, mo)
+
+
+def _ls_bookkeeping(rho, drho, success, adapt=True):
+    """line_search.cuh:65-79 in float32: what one line search does to (rho, drho) -- the solve resets drho at its end
+    (bsqp.cuh:189), so a teacher-forced chain of one-iteration solves carries it by hand"""
+    f = np.float32
+    rho, drho = rho.astype(f).copy(), drho.astype(f).copy()
+    if adapt:
+        mult = np.where(success, np.minimum(drho / f(1.2), f(1) / f(1.2)), np.maximum(drho * f(1.2), f(1.2))).astype(f)
+        drho = mult
+        rho = np.minimum(np.maximum(rho * mult, f(1e-8)), f(10.0)).astype(f)
+    return rho, drho
+
+
+@pytest.mark.parametrize("plant,N,B,tight", [("indy7", 32, 8, False), ("indy7", 32, 8, True), ("iiwa14", 32, 4, False), ("iiwa14", 64, 4, False),
+                                             ("iiwa14", 128, 2, False)])
+def test_teacher_forced_iterations(plant, N, B, tight):
+    """Ten SQP iterations, each one started on BOTH sides from the oracle's state after the previous one (iterate, lambda, rho, drho):
+    iterations >= 2 -- warm-started PCG, rho / drho adaptation, running merit -- are compared map by map, so the problem's
+    sensitivity cannot hide a state-handling bug and no trajectory is excluded.  (Convergence flags do not carry over between
+    one-iteration solves; test_early_exit_on_device covers them.)"""
+    over = dict(max_sqp_iters=1, **(TIGHT if tight else {}))
+    nat, orc, pr = make(plant, N, B, 2.0, **over)
+    xs, ref = pr["x_s"], pr["ref"]
+    xu = pr["xu"].copy()
+    lam = np.zeros((B, N + 2, nat.nx), np.float32)
+    rho = np.full(B, DEFAULT_SOLVER_PARAMS["rho"], np.float32)
+    drho = np.ones(B, np.float32)
+    tol_dz, tol_m, tol_x = (2e-4, 2e-4, 1e-4) if tight else (5e-3, 2e-3, 2e-3)
+    worst = dict(dz=0.0, merit=0.0, xu=0.0, pcg=0, ambiguous=0)
+    for it in range(10):
+        for s in (nat, orc):
+            s.set_rho_penalty_batch(rho, False)
+            s.set_drho_batch(drho, False)
+        nat.write("lambda", lam)
+        orc.set_lambda(lam)
+        rg = nat.solve(xu, DT, xs, ref)
+        ro = orc.solve(xu, DT, xs, ref)
+        dz_g, dz_o = nat.read("dz").reshape(B, -1), orc.buf("dz")
+        m_g = nat.read("merit").reshape(B, 8)
+        m_o = orc.merit(xu, xs, ref, DT, num_alphas=8)                      # from the oracle's dz of this iteration
+        pd = int(np.abs(rg["pcg_iters"][0].astype(int) - ro["pcg_iters"][0]).max())
+        worst["pcg"] = max(worst["pcg"], pd)
+        assert pd <= (max(2, int(0.02 * ro["pcg_iters"][0].max())) if not tight else 1000), (it, rg["pcg_iters"][0], ro["pcg_iters"][0])
+        e_dz = np.abs(dz_g - dz_o).max(axis=1) / np.maximum(1e-3, np.abs(dz_o).max(axis=1))
+        e_m = np.abs(m_g - m_o).max(axis=1) / np.maximum(1.0, np.abs(m_o).max(axis=1))
+        worst["dz"], worst["merit"] = max(worst["dz"], float(e_dz.max())), max(worst["merit"], float(e_m.max()))
+        assert e_dz.max() < tol_dz, (it, e_dz)
+        assert e_m.max() < tol_m, (it, e_m)
+        assert relscale(rg["initial_merit"], ro["initial_merit"]) < 1e-5
+        # the decision: identical wherever the oracle's own margin exceeds the merit tolerance (SURVEY 8(c): otherwise the argmin / the
+        # accept test is legitimately ambiguous)
+        cur = ro["initial_merit"]
+        srt = np.sort(m_o, axis=1)
+        margin = np.minimum(srt[:, 1] - srt[:, 0], np.abs(srt[:, 0] - cur)) / np.maximum(1.0, np.abs(cur))
+        sure = margin > 2 * tol_m
+        worst["ambiguous"] += int((~sure).sum())
+        np.testing.assert_array_equal(rg["ls_step_size"][0][sure], ro["ls_step_size"][0][sure])
+        same = rg["ls_step_size"][0] == ro["ls_step_size"][0]
+        np.testing.assert_array_equal(nat.read("rho")[same], orc.buf("rho")[same])
+        e_x = traj_err(rg["XU"], ro["XU"])
+        worst["xu"] = max(worst["xu"], float(e_x[same].max()) if same.any() else 0.0)
+        assert e_x[same].max() < tol_x, (it, e_x)
+        # the oracle's state is the next starting point of both
+        success = ro["ls_step_size"][0] > 0
+        rho_n, drho_n = _ls_bookkeeping(rho, drho, success)
+        np.testing.assert_array_equal(rho_n, orc.buf("rho"))                # the hand-carried rule IS the oracle's rule
+        xu, lam, rho, drho = ro["XU"].copy(), orc.buf("lambda"), rho_n, drho_n
+    _report("teacher_forced", plant=plant, N=N, tight=bool(tight), **worst)
+    assert worst["ambiguous"] <= B   # the margin rule must not turn the decision check into a formality (10 B decisions in all)
 
 
 @pytest.mark.parametrize("plant,N,B,fstd", [("indy7", 32, 32, 0.0), ("iiwa14", 16, 8, 3.0), ("indy7", 4, 4, 1.0)])
@@ -178,13 +288,12 @@ def test_full_solve_parity(plant, N, B, fstd):
     assert relscale(rg["initial_merit"], ro["initial_merit"]) < 1e-5
     np.testing.assert_array_equal(rg["ls_step_size"][0], ro["ls_step_size"][0])     # first iteration: identical decisions
     assert np.abs(rg["pcg_iters"][0].astype(int) - ro["pcg_iters"][0]).max() <= 1
-    same = np.all(rg["ls_step_size"] == ro["ls_step_size"], axis=0)  # trajectories whose discrete decisions agree over all 3 iterations
-    assert same.mean() >= 0.75
-    # a 1e-4-relative PCG exit leaves ~1e-2 slack in lambda: iterates of agreeing trajectories stay within a few 1e-3 (see the golden test)
-    err = traj_err(rg["XU"], ro["XU"])[same]
-    assert np.median(err) < 2e-3 and np.mean(err < 1e-2) >= 0.9
-    merr = np.abs(rg["final_merit"] - ro["final_merit"])[same] / ro["final_merit"][same]
-    assert np.median(merr) < 1e-2
+    # three free-running iterations at the DEFAULT PCG tolerance: every trajectory stays within the fp32 sensitivity of the problem
+    # (fp32 vs float64 of the same source: 1e-3 .. 6e-2 here); the per-iteration maps are pinned by
+    # test_teacher_forced_iterations, the floor-PCG iterates by test_three_iterations_against_float64
+    err = traj_err(rg["XU"], ro["XU"])
+    _report("free_3it_default", plant=plant, N=N, xu=err.max(), same=float(np.all(rg["ls_step_size"] == ro["ls_step_size"], axis=0).mean()))
+    assert err.max() < 5e-2, err
     # result-dict surface of PyBSQP::solve (bindings.cu:96-145)
     assert rg["XU"].dtype == np.float32 and rg["sqp_iters"].dtype == np.int32 and rg["pcg_iters"].shape == (3, B)
     assert rg["ls_min_merit"].shape == (3, B) and rg["pcg_times_us"].shape == (3,) and np.all(rg["pcg_times_us"] == 0)
@@ -397,8 +506,87 @@ def test_full_size_properties():
     orc = OracleSolver("indy7", N, len(idx), dt=DT, **p)
     fm = orc.merit(out["XU"][idx], pr["x_s"][idx], pr["ref"][idx], DT, num_alphas=1, zero_dz=True)[:, 0]
     assert relscale(out["final_merit"][idx], fm) < 1e-5
-    # and the oracle, solving those rows itself, lands on the same steps for the large majority
+    # and the oracle, solving those rows itself: identical first-iteration decisions on every sampled row
     ro = orc.solve(pr["xu"][idx], DT, pr["x_s"][idx], pr["ref"][idx])
-    same = np.all(ro["ls_step_size"] == out["ls_step_size"][:, idx], axis=0)
-    assert same.mean() >= 0.6
-    assert np.median(traj_err(out["XU"][idx], ro["XU"])[same]) < 5e-3
+    np.testing.assert_array_equal(ro["ls_step_size"][0], out["ls_step_size"][0][idx])
+    assert np.abs(ro["pcg_iters"][0].astype(int) - out["pcg_iters"][0][idx]).max() <= 1
+
+
+def test_c3_iiwa14_N128_B256():
+    """BASELINE config C3 (iiwa14, N=128, batch=256): the whole driver loop on the long-horizon path (stand-alone Schur kernels, the
+    N = 128 PCG kernel, un-fused dz / merit / line search) at full size.  Size-independent properties + the oracle on a sample of rows;
+    the oracle comparisons of the iterates themselves at this N are test_three_iterations_against_float64[iiwa14-128-4] and
+    test_teacher_forced_iterations[iiwa14-128-2]."""
+    from gato_amd._lib import NativeSolver
+    from oracle.oracle import OracleSolver
+    plant, N, B = "iiwa14", 128, 256
+    p = dict(DEFAULT_SOLVER_PARAMS, max_sqp_iters=4)
+    pr = fig8_problem(plant, N, B)
+    big = NativeSolver(plant, N, B, dt=DT, **p)
+    out = big.solve(pr["xu"], DT, pr["x_s"], pr["ref"])
+    assert out["iters_done"] == 4 and np.all(np.isfinite(out["XU"])) and np.all(out["final_merit"] < out["initial_merit"])
+    mm = np.vstack([out["initial_merit"][None], out["ls_min_merit"]])
+    assert np.all(np.diff(mm, axis=0) <= 0)
+    # batch independence: rows solved alone give the same bits (what lets the batch shard over GPUs without a collective)
+    sl = slice(64, 68)
+    part = NativeSolver(plant, N, 4, dt=DT, **p)
+    o = part.solve(pr["xu"][sl], DT, pr["x_s"][sl], pr["ref"][sl])
+    np.testing.assert_array_equal(o["XU"], out["XU"][sl])
+    np.testing.assert_array_equal(o["pcg_iters"], out["pcg_iters"][:, sl])
+    # checksum of the output: final merit == oracle merit of the returned iterates, on a sample of rows
+    idx = np.arange(0, B, 32)
+    orc = OracleSolver(plant, N, len(idx), dt=DT, **p)
+    fm = orc.merit(out["XU"][idx], pr["x_s"][idx], pr["ref"][idx], DT, num_alphas=1, zero_dz=True)[:, 0]
+    assert relscale(out["final_merit"][idx], fm) < 1e-5
+    # the oracle solving the sampled rows itself: the first iteration's decisions of every sampled row
+    ro = orc.solve(pr["xu"][idx], DT, pr["x_s"][idx], pr["ref"][idx])
+    np.testing.assert_array_equal(ro["ls_step_size"][0], out["ls_step_size"][0][idx])
+    assert np.abs(ro["pcg_iters"][0].astype(int) - out["pcg_iters"][0][idx]).max() <= 1
+    assert relscale(out["initial_merit"][idx], ro["initial_merit"]) < 1e-5
+
+
+def test_c5_shard_iiwa14_N64_B512():
+    """BASELINE config C5, one GPU's shard (iiwa14 N=64, 512 trajectories of the hyper-parameter sweep: per-trajectory rho over nine
+    decades, dt = 0.05, mu = 1, pcg_tol 1e-3, a cost tuple of the grid): properties at full size + the oracle on a sample of rows."""
+    from gato_amd._lib import NativeSolver
+    from gato_amd.bsqp.workloads import hparam_problem
+    from oracle.oracle import OracleSolver
+    plant, N, B = "iiwa14", 64, 512
+    pr = hparam_problem(plant, N, B, shard=3)
+    p = dict(pr["params"], max_sqp_iters=5)
+    dt = pr["dt"]
+    big = NativeSolver(plant, N, B, dt=dt, **p)
+    big.set_rho_penalty_batch(pr["rho"])
+    out = big.solve(pr["xu"], dt, pr["x_s"], pr["ref"])
+    assert out["iters_done"] == 5 and np.all(np.isfinite(out["XU"])) and np.all(out["final_merit"] <= out["initial_merit"])
+    mm = np.vstack([out["initial_merit"][None], out["ls_min_merit"]])
+    assert np.all(np.diff(mm, axis=0) <= 0)
+    sl = slice(300, 304)
+    part = NativeSolver(plant, N, 4, dt=dt, **p)
+    part.set_rho_penalty_batch(pr["rho"][sl])
+    o = part.solve(pr["xu"][sl], dt, pr["x_s"][sl], pr["ref"][sl])
+    np.testing.assert_array_equal(o["XU"], out["XU"][sl])
+    idx = np.arange(5, B, 64)
+    orc = OracleSolver(plant, N, len(idx), dt=dt, **p)
+    orc.set_rho_penalty_batch(pr["rho"][idx])
+    fm = orc.merit(out["XU"][idx], pr["x_s"][idx], pr["ref"][idx], dt, num_alphas=1, zero_dz=True)[:, 0]
+    assert relscale(out["final_merit"][idx], fm) < 1e-4
+    ro = orc.solve(pr["xu"][idx], dt, pr["x_s"][idx], pr["ref"][idx])
+    np.testing.assert_array_equal(ro["ls_step_size"][0], out["ls_step_size"][0][idx])
+    assert relscale(out["initial_merit"][idx], ro["initial_merit"]) < 1e-5
+
+
+def test_rho_reset_rule_without_adaptation():
+    """line_search.cuh:77-79: with adaptation off and a caller's rho above RHO_MAX a failed line search puts rho back to RHO_INIT.
+    An absurd rho makes the step useless; whatever the searches decide, kernel and oracle must leave the same rho behind."""
+    nat, orc, pr = make("indy7", 8, 4, 0.0, max_sqp_iters=2)
+    rho = np.array([20.0, 0.01, 50.0, 5.0], np.float32)
+    for s in (nat, orc):
+        s.set_rho_adaptation(False)
+        s.set_rho_penalty_batch(rho, True)
+    rg = nat.solve(pr["xu"], DT, pr["x_s"], pr["ref"])
+    ro = orc.solve(pr["xu"], DT, pr["x_s"], pr["ref"])
+    np.testing.assert_array_equal(rg["ls_step_size"], ro["ls_step_size"])
+    np.testing.assert_array_equal(nat.read("rho"), orc.buf("rho"))
+    failed = np.any(ro["ls_step_size"] < 0, axis=0)
+    assert np.all(orc.buf("rho")[failed & (rho > 10)] == np.float32(1e-3)) and np.all(orc.buf("rho")[~failed] == rho[~failed])
