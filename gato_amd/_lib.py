@@ -17,7 +17,7 @@ SYMBOLS = [
     "gato_set_mu_batch", "gato_set_pcg_tol_batch", "gato_reset_dual", "gato_reset_rho", "gato_set_rho_adaptation", "gato_sim_forward",
     "gato_ee_pos", "gato_debug_read", "gato_debug_write", "gato_debug_stage", "gato_set_profiling", "gato_get_stage_times_us",
     "gato_last_error", "gato_version", "gato_reset_async", "gato_copy_final_merit_device", "gato_set_cost_weights_batch",
-    "gato_synchronize", "gato_sim_forward_device",
+    "gato_synchronize", "gato_sim_forward_device", "gato_select_best", "gato_select_best_device",
 ]
 
 
@@ -35,20 +35,26 @@ class GatoError(RuntimeError):
 _lib = None
 
 
+def preload_torch():
+    """torch (when installed) is imported BEFORE libgato_hip.so so that both share torch's bundled libamdhip64 instead of loading a
+    second HIP runtime into the process."""
+    if "torch" not in sys.modules and os.environ.get("GATO_NO_TORCH", "0") != "1":
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
+
+
 def load():
-    """Loads libgato_hip.so.  torch (when installed) is imported FIRST so that both share torch's bundled libamdhip64 instead of
-    loading a second HIP runtime into the process."""
+    """Loads libgato_hip.so for the ctypes binding (the tests' back door to the stage / debug entry points; the product's Python
+    classes are the compiled ones of gato_amd._gato_ext)."""
     global _lib
     if _lib is not None:
         return _lib
     if not os.path.exists(LIB_PATH):
         raise GatoError("libgato_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C gato_amd/csrc`."
                         % LIB_PATH)
-    if "torch" not in sys.modules and os.environ.get("GATO_NO_TORCH", "0") != "1":
-        try:
-            import torch  # noqa: F401
-        except Exception:
-            pass
+    preload_torch()
     L = C.CDLL(LIB_PATH)
     fp, ip, vp = C.POINTER(C.c_float), C.POINTER(C.c_int32), C.c_void_p
     L.gato_default_params.argtypes = [C.POINTER(GatoParams)]
@@ -79,6 +85,8 @@ def load():
     L.gato_reset_async.argtypes = [vp, C.c_int, C.c_int, vp]
     L.gato_copy_final_merit_device.argtypes = [vp, vp, vp]
     L.gato_synchronize.argtypes = [vp]
+    L.gato_select_best.argtypes = [vp, fp, fp, fp, C.c_float, C.POINTER(C.c_int), fp]
+    L.gato_select_best_device.argtypes = [vp, vp, vp, vp, C.c_float, vp, vp, vp]
     L.gato_sim_forward_device.argtypes = [vp, vp, vp, vp, C.c_float, vp]
     L.gato_last_error.restype = C.c_char_p
     L.gato_version.restype = C.c_char_p
@@ -230,6 +238,14 @@ class NativeSolver:
     def sim_forward_device(self, d_xkp1, d_xk, d_uk, dt, stream=0):
         """BSQP::sim_forward on raw device pointers (ints), asynchronous on `stream` (bsqp.cuh:91)."""
         _chk(load().gato_sim_forward_device(self.h, C.c_void_p(d_xkp1), C.c_void_p(d_xk), C.c_void_p(d_uk), float(dt), C.c_void_p(stream)))
+
+    def select_best(self, x_last, u_last, x_meas, dt):
+        """(best index, errors[B]): MPC hypothesis selection on the device (mpc_controller.py:294-309)"""
+        err = np.zeros(self.B, np.float32)
+        best = C.c_int(0)
+        _chk(load().gato_select_best(self.h, _p(_f32(x_last, (self.nx,))), _p(_f32(u_last, (self.nu,))), _p(_f32(x_meas, (self.nx,))), float(dt),
+                                     C.byref(best), _p(err)))
+        return best.value, err
 
     def synchronize(self):
         _chk(load().gato_synchronize(self.h))

@@ -1957,6 +1957,72 @@ __global__ __launch_bounds__(256) void sim_forward_kernel(float* __restrict__ xk
     }
 }
 
+// Hypothesis selection of the MPC loop in ONE launch (mpc_controller.py:294-309: sim_forward, per-hypothesis distance to the measured
+// state, arg-min): lane b integrates the shared (x_last, u_last) under wrench b, leaves x_next_b and err_b = |x_next_b - x_meas|_2;
+// the last workgroup to finish (device counter) takes the first minimum over the batch like np.argmin.
+template<class M>
+__global__ __launch_bounds__(256) void select_best_kernel(float* __restrict__ xkp1, float* __restrict__ err, int* __restrict__ best,
+                                                          uint32_t* __restrict__ count, const float* __restrict__ xk, const float* __restrict__ uk,
+                                                          const float* __restrict__ xmeas, const float* __restrict__ f_ext, int B, float dt)
+{
+    constexpr int NQ = M::NQ, NX = 2 * NQ;
+    __shared__ float s_e[256];
+    __shared__ int s_i[256];
+    __shared__ bool s_last;
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) {
+        float x[NX], u[NQ], fe[6], qdd[NQ];
+#pragma unroll
+        for (int i = 0; i < NX; i++) x[i] = xk[i];
+#pragma unroll
+        for (int i = 0; i < NQ; i++) u[i] = uk[i];
+#pragma unroll
+        for (int i = 0; i < 6; i++) fe[i] = f_ext[6 * b + i];
+        RBD<M> d;
+        d.set_q(x);
+        d.forward_dynamics(x + NQ, u, fe, qdd);
+        float e2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NQ; i++) {
+            const float qdn = x[NQ + i] + dt * qdd[i];
+            const float qn = (float)((double)(x[i] + dt * x[NQ + i]) + 0.5 * (double)qdd[i] * (double)dt * (double)dt);
+            xkp1[(size_t)b * NX + NQ + i] = qdn;
+            xkp1[(size_t)b * NX + i] = qn;
+            const float dq = qn - xmeas[i], dv = qdn - xmeas[NQ + i];
+            e2 += dq * dq;
+            e2 += dv * dv;
+        }
+        err[b] = sqrtf(e2);
+    }
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = (atomicAdd(count, 1u) == gridDim.x - 1);
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    float be = 3.4e38f;
+    int bi = 0x7fffffff;
+    for (int i = threadIdx.x; i < B; i += blockDim.x) {
+        const float e = __builtin_nontemporal_load(err + i);
+        if (e < be) { be = e; bi = i; }   // ascending i per thread: the first minimum of its stride
+    }
+    s_e[threadIdx.x] = be;
+    s_i[threadIdx.x] = bi;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            const float e2 = s_e[threadIdx.x + off];
+            const int i2 = s_i[threadIdx.x + off];
+            if (e2 < s_e[threadIdx.x] || (e2 == s_e[threadIdx.x] && i2 < s_i[threadIdx.x])) { s_e[threadIdx.x] = e2; s_i[threadIdx.x] = i2; }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        *best = s_i[0] == 0x7fffffff ? 0 : s_i[0];
+        *count = 0;  // ready for the next call
+    }
+}
+
 // end-effector positions of a batch of configurations (the facade's ee_pos; the reference uses pinocchio FK, interface.py:212-214)
 template<class M>
 __global__ __launch_bounds__(256) void ee_pos_kernel(float* __restrict__ out, const float* __restrict__ q, int n)

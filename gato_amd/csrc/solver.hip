@@ -64,6 +64,8 @@ struct GatoSolver {
     // Schur complement is formed inside it.  Tuning overrides GATO_PCG_VARIANT / GATO_PCG_FOLD are read there, never in the solve loop.
     int pcg_choice, pcg_fold, pcg_fused;
     float *d_sim_x, *d_sim_u, *d_sim_out;  // staging of sim_forward ([nx], [nu], [B][nx]), allocated with the solver
+    float *d_sel_xm, *d_sel_err;           // gato_select_best: measured state [nx], per-hypothesis error [B]
+    int32_t* d_sel_best;                   // [0] arg-min, [1] completion counter of the selection kernel
     float *d_ee_q, *d_ee_out;              // staging of ee_pos, grown on demand
     size_t ee_cap;
     uint32_t max_iters_alloc;
@@ -162,6 +164,7 @@ static int create_impl(GatoSolver* s, int plant, int N, int B, const GatoParams*
     DA(s->d_xu_own, (size_t)B * s->traj); DA(s->d_xs_own, (size_t)B * nx); DA(s->d_ref_own, (size_t)B * 6 * N);
     DA(s->d_merit_init0, B); DA(s->d_drho_init, B); DA(s->d_rho_init, B);
     DA(s->d_sim_x, nx); DA(s->d_sim_u, nu); DA(s->d_sim_out, (size_t)B * nx);
+    DA(s->d_sel_xm, nx); DA(s->d_sel_err, B); DA(s->d_sel_best, 2);
 #undef DA
     s->d_ee_q = s->d_ee_out = nullptr;
     s->ee_cap = 0;
@@ -712,6 +715,42 @@ extern "C" int gato_sim_forward(GatoSolver* s, float* xkp1, const float* xk, con
     rc = gato_sim_forward_device(s, s->d_sim_out, s->d_sim_x, s->d_sim_u, dt, nullptr);
     if (rc) return rc;
     HIPCHK(hipMemcpy(xkp1, s->d_sim_out, (size_t)s->B * s->nx * sizeof(float), hipMemcpyDeviceToHost));  // blocking on the null stream
+    return GATO_OK;
+}
+
+// evaluate_best_trajectory of the MPC loop (mpc_controller.py:294-309) in one launch: x_next under every stored wrench hypothesis,
+// err_b = |x_next_b - x_meas|_2 (fp32 on the device; the reference forms it in float64 on the host), best = the first arg-min.
+extern "C" int gato_select_best_device(GatoSolver* s, const float* d_x_last, const float* d_u_last, const float* d_x_meas, float dt, int32_t* d_best,
+                                       float* d_err, void* stream)
+{
+    if (!s || !d_x_last || !d_u_last || !d_x_meas || !d_best || !d_err) return fail(GATO_ERR_INVALID, "null argument");
+    GUARD(s);
+    hipStream_t st = (hipStream_t)stream;
+    uint32_t* cnt = reinterpret_cast<uint32_t*>(s->d_sel_best + 1);
+    if (s->plant == GATO_PLANT_INDY7)
+        hipLaunchKernelGGL((select_best_kernel<Indy7>), dim3(cdiv(s->B, 256)), dim3(256), 0, st, s->d_sim_out, d_err, d_best, cnt, d_x_last, d_u_last, d_x_meas,
+                           s->bf.f_ext, s->B, dt);
+    else
+        hipLaunchKernelGGL((select_best_kernel<Iiwa14>), dim3(cdiv(s->B, 256)), dim3(256), 0, st, s->d_sim_out, d_err, d_best, cnt, d_x_last, d_u_last, d_x_meas,
+                           s->bf.f_ext, s->B, dt);
+    HIPCHK(hipGetLastError());
+    return GATO_OK;
+}
+extern "C" int gato_select_best(GatoSolver* s, const float* x_last, const float* u_last, const float* x_meas, float dt, int* best, float* errors)
+{
+    if (!s || !x_last || !u_last || !x_meas || !best) return fail(GATO_ERR_INVALID, "null argument");
+    GUARD(s);
+    int rc = sync_last(s);
+    if (rc) return rc;
+    HIPCHK(hipMemcpy(s->d_sim_x, x_last, s->nx * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(s->d_sim_u, u_last, s->nu * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(s->d_sel_xm, x_meas, s->nx * sizeof(float), hipMemcpyHostToDevice));
+    rc = gato_select_best_device(s, s->d_sim_x, s->d_sim_u, s->d_sel_xm, dt, s->d_sel_best, s->d_sel_err, nullptr);
+    if (rc) return rc;
+    int32_t b = 0;
+    HIPCHK(hipMemcpy(&b, s->d_sel_best, sizeof(int32_t), hipMemcpyDeviceToHost));
+    *best = (int)b;
+    if (errors) HIPCHK(hipMemcpy(errors, s->d_sel_err, (size_t)s->B * sizeof(float), hipMemcpyDeviceToHost));
     return GATO_OK;
 }
 

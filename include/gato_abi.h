@@ -110,6 +110,14 @@ int gato_sim_forward(GatoSolver* s, float* xkp1, const float* xk, const float* u
  * (d_xkp1 [B][nx], d_xk [nx], d_uk [nu]), enqueued on `stream` without a host synchronisation. */
 int gato_sim_forward_device(GatoSolver* s, float* d_xkp1, const float* d_xk, const float* d_uk, float dt, void* stream);
 
+/* Hypothesis selection of the MPC loop, MPC_GATO.evaluate_best_trajectory (python/bsqp/mpc_controller.py:294-309), in one launch:
+ * sim_forward of the shared (x_last, u_last) under the B stored wrenches, errors[b] = |x_next_b - x_meas|_2 and *best = the first
+ * arg-min (np.argmin).  errors ([B], host) may be NULL.  The _device form takes device pointers, is enqueued on `stream` and does not
+ * synchronise; d_best is one int32. */
+int gato_select_best(GatoSolver* s, const float* x_last, const float* u_last, const float* x_meas, float dt, int* best, float* errors);
+int gato_select_best_device(GatoSolver* s, const float* d_x_last, const float* d_u_last, const float* d_x_meas, float dt, int32_t* d_best,
+                            float* d_errors, void* stream);
+
 /* End-effector positions [n][3] of n joint configurations [n][nq] (host arrays): what interface.BSQP.ee_pos obtains from
  * pinocchio in the reference (python/bsqp/interface.py:212-214), computed with the solver's own kinematics. */
 int gato_ee_pos(GatoSolver* s, const float* q, int n, float* out);

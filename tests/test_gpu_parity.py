@@ -161,7 +161,7 @@ def _report(name, **kw):
         d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
         os.makedirs(d, exist_ok=True)
         with open(os.path.join(d, "parity_measured.jsonl"), "a") as f:
-            f.write(json.dumps(dict(test=name, **{k: (float(v) if np.isscalar(v) else v) for k, v in kw.items()})) + "\n")
+            f.write(json.dumps(dict(test=name, **{k: (v if isinstance(v, (str, bool, int)) else float(v)) for k, v in kw.items()})) + "\n")
     except OSError:
         pass
 

@@ -19,7 +19,9 @@ def test_modules_and_classes_exist(plant, N):
         for meth in ("solve", "reset_dual", "set_f_ext_batch", "set_rho_penalty_batch", "set_drho_batch", "set_mu_batch", "set_pcg_tol_batch",
                      "sim_forward", "reset_rho", "set_rho_adaptation"):  # bindings.cu:224-237
             assert callable(getattr(cls, meth))
-    assert inspect.signature(m.BSQP_1_float.set_rho_penalty_batch).parameters["set_as_reset_default"].default is True
+    assert "set_as_reset_default: bool = True" in m.BSQP_1_float.set_rho_penalty_batch.__doc__        # py::arg(...) = true, bindings.cu:229-230
+    from gato_amd import _gato_ext                                      # the classes are the COMPILED pybind11 class with (plant, N, B) fixed
+    assert issubclass(m.BSQP_1_float, _gato_ext.BSQP) and type(_gato_ext.BSQP).__name__ == "pybind11_type"
     assert not hasattr(m, "BSQP_0_float") and not hasattr(m, "BSQP_8_double")
 
 
