@@ -62,7 +62,7 @@ def test_select_best_against_oracle(plant, B):
     best, err = nat.select_best(xk, uk, x_meas, 0.008)
     eo = np.linalg.norm(xo.astype(np.float32) - x_meas[None, :], axis=1)
     assert best == int(np.argmin(eo)) == truth
-    np.testing.assert_allclose(err, eo, rtol=2e-4, atol=2e-7)
+    np.testing.assert_allclose(err, eo, rtol=2e-4, atol=2e-6)   # the true hypothesis' error is rounding noise of ~1e-7
     # twice in a row: the completion counter of the selection kernel resets itself
     best2, err2 = nat.select_best(xk, uk, x_meas, 0.008)
     assert best2 == best and np.array_equal(err2, err)
