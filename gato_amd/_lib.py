@@ -18,6 +18,7 @@ SYMBOLS = [
     "gato_ee_pos", "gato_debug_read", "gato_debug_write", "gato_debug_stage", "gato_set_profiling", "gato_get_stage_times_us",
     "gato_last_error", "gato_version", "gato_reset_async", "gato_copy_final_merit_device", "gato_set_cost_weights_batch",
     "gato_synchronize", "gato_sim_forward_device", "gato_select_best", "gato_select_best_device",
+    "gato_plant_rk4", "gato_fk_placements",
 ]
 
 
@@ -85,6 +86,8 @@ def load():
     L.gato_reset_async.argtypes = [vp, C.c_int, C.c_int, vp]
     L.gato_copy_final_merit_device.argtypes = [vp, vp, vp]
     L.gato_synchronize.argtypes = [vp]
+    L.gato_plant_rk4.argtypes = [vp, fp, fp, C.c_int, fp, C.c_float]
+    L.gato_fk_placements.argtypes = [C.c_int, fp, C.POINTER(C.c_double)]
     L.gato_select_best.argtypes = [vp, fp, fp, fp, C.c_float, C.POINTER(C.c_int), fp]
     L.gato_select_best_device.argtypes = [vp, vp, vp, vp, C.c_float, vp, vp, vp]
     L.gato_sim_forward_device.argtypes = [vp, vp, vp, vp, C.c_float, vp]
@@ -108,6 +111,14 @@ def _f32(a, shape=None):
 
 def _p(a):
     return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def fk_placements(plant, q):
+    """(R[nq,3,3], p[nq,3]) float64: world placements of the joint frames from the library's kinematic tables (no device needed)"""
+    nq = NQ[plant]
+    out = np.zeros((nq, 12), np.float64)
+    _chk(load().gato_fk_placements(PLANTS[plant], _p(_f32(q, (nq,))), out.ctypes.data_as(C.POINTER(C.c_double))))
+    return out[:, :9].reshape(nq, 3, 3).copy(), out[:, 9:].copy()
 
 
 PARAM_ORDER = [f[0] for f in GatoParams._fields_]
@@ -246,6 +257,13 @@ class NativeSolver:
         _chk(load().gato_select_best(self.h, _p(_f32(x_last, (self.nx,))), _p(_f32(u_last, (self.nu,))), _p(_f32(x_meas, (self.nx,))), float(dt),
                                      C.byref(best), _p(err)))
         return best.value, err
+
+    def plant_rk4(self, x, u_seq, f_ext6, sim_dt):
+        """nsteps = len(u_seq) RK4 steps of the library's forward dynamics (the MPC loop's plant simulator); returns the new state"""
+        x = np.array(x, dtype=np.float32).reshape(self.nx)
+        u = _f32(u_seq).reshape(-1, self.nu)
+        _chk(load().gato_plant_rk4(self.h, _p(x), _p(u), int(u.shape[0]), _p(_f32(f_ext6, (6,))), float(sim_dt)))
+        return x
 
     def synchronize(self):
         _chk(load().gato_synchronize(self.h))

@@ -101,6 +101,19 @@ class BSQP:
     def sim_forward(self, xk, uk, sim_dt):
         return self.solver.sim_forward(np.asarray(xk, dtype=np.float32), np.asarray(uk, dtype=np.float32), sim_dt)
 
+    # ---- extensions used by the MPC loop (not in the reference facade) ----
+    def select_best(self, x_last, u_last, x_meas, sim_dt):
+        """(best index, errors[B]): sim_forward + per-hypothesis error + arg-min in ONE device launch (gato_select_best); what
+        MPC_GATO.evaluate_best_trajectory assembles from sim_forward and numpy in the reference (mpc_controller.py:294-309)"""
+        best, err = self.solver.select_best(np.asarray(x_last, np.float32), np.asarray(u_last, np.float32), np.asarray(x_meas, np.float32), sim_dt)
+        return int(best), np.asarray(err)
+
+    def plant_rk4(self, x, u_seq, f_ext6, sim_dt):
+        """len(u_seq) RK4 steps of the library's own forward dynamics under a constant spatial wrench: the plant of the closed loop
+        (the reference integrates pinocchio's aba, common.py:49-91)"""
+        return np.asarray(self.solver.plant_rk4(np.asarray(x, np.float32), np.asarray(u_seq, np.float32).reshape(-1, self.nu),
+                                                np.asarray(f_ext6, np.float32), sim_dt))
+
     def set_f_ext_B(self, f_ext_B):
         self.f_ext_B = np.asarray(f_ext_B, dtype=np.float32)
         self.solver.set_f_ext_batch(self.f_ext_B)

@@ -2023,6 +2023,66 @@ __global__ __launch_bounds__(256) void select_best_kernel(float* __restrict__ xk
     }
 }
 
+// The plant of the closed MPC loop: `nsteps` RK4 steps of the arm's forward dynamics under a constant wrench on the last link, one
+// control vector per step -- what python/bsqp/common.py:49-91 (`rk4`: k1..k4 from the articulated-body forward dynamics, revolute
+// joints so pin.integrate is q + v h) does with pinocchio between two solves of MPC_GATO.run_mpc_fig8 (mpc_controller.py:199-218).
+// Here the dynamics are the library's own (rbd.hpp, the tables the solver optimises with): one lane per plant instance.
+template<class M>
+__global__ __launch_bounds__(64) void plant_rk4_kernel(float* __restrict__ x_io, const float* __restrict__ u_seq, const float* __restrict__ f_ext,
+                                                       int nsteps, float h, int nplants)
+{
+    constexpr int NQ = M::NQ, NX = 2 * NQ;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nplants) return;
+    float q[NQ], v[NQ], fe[6];
+#pragma unroll
+    for (int i = 0; i < NQ; i++) { q[i] = x_io[(size_t)p * NX + i]; v[i] = x_io[(size_t)p * NX + NQ + i]; }
+#pragma unroll
+    for (int i = 0; i < 6; i++) fe[i] = f_ext[6 * p + i];
+    const float hh = 0.5f * h;
+    for (int s = 0; s < nsteps; s++) {
+        float u[NQ];
+#pragma unroll
+        for (int i = 0; i < NQ; i++) u[i] = u_seq[((size_t)p * nsteps + s) * NQ + i];
+        float k1v[NQ], k2v[NQ], k3v[NQ], k4v[NQ], k2q[NQ], k3q[NQ], k4q[NQ], qs[NQ];
+        {
+            RBD<M> d;
+            d.set_q(q);
+            d.forward_dynamics(v, u, fe, k1v);
+        }
+#pragma unroll
+        for (int i = 0; i < NQ; i++) { qs[i] = q[i] + v[i] * hh; k2q[i] = v[i] + k1v[i] * hh; }
+        {
+            RBD<M> d;
+            d.set_q(qs);
+            d.forward_dynamics(k2q, u, fe, k2v);
+        }
+#pragma unroll
+        for (int i = 0; i < NQ; i++) { qs[i] = q[i] + k2q[i] * hh; k3q[i] = v[i] + k2v[i] * hh; }
+        {
+            RBD<M> d;
+            d.set_q(qs);
+            d.forward_dynamics(k3q, u, fe, k3v);
+        }
+#pragma unroll
+        for (int i = 0; i < NQ; i++) { qs[i] = q[i] + k3q[i] * h; k4q[i] = v[i] + k3v[i] * h; }
+        {
+            RBD<M> d;
+            d.set_q(qs);
+            d.forward_dynamics(k4q, u, fe, k4v);
+        }
+#pragma unroll
+        for (int i = 0; i < NQ; i++) {
+            const float avg = (v[i] + 2.f * k2q[i] + 2.f * k3q[i] + k4q[i]) / 6.f;
+            const float vn = v[i] + (h / 6.f) * (k1v[i] + 2.f * k2v[i] + 2.f * k3v[i] + k4v[i]);
+            q[i] = q[i] + avg * h;
+            v[i] = vn;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NQ; i++) { x_io[(size_t)p * NX + i] = q[i]; x_io[(size_t)p * NX + NQ + i] = v[i]; }
+}
+
 // end-effector positions of a batch of configurations (the facade's ee_pos; the reference uses pinocchio FK, interface.py:212-214)
 template<class M>
 __global__ __launch_bounds__(256) void ee_pos_kernel(float* __restrict__ out, const float* __restrict__ q, int n)

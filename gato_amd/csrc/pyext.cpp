@@ -158,6 +158,22 @@ class PyBSQP {
         return py::make_tuple(best, err);
     }
 
+    // the MPC loop's plant simulator (common.py:49-91 `rk4`): len(u_seq) RK4 steps of the library's own forward dynamics
+    py::array_t<float> plant_rk4(farray x, farray u_seq, farray f_ext6, float sim_dt)
+    {
+        need(x, nx_, "x");
+        need(f_ext6, 6, "f_ext6");
+        if (u_seq.size() % nu_) throw py::value_error("u_seq: expected [nsteps][nu] floats");
+        const int nsteps = (int)(u_seq.size() / nu_);
+        py::array_t<float> out((py::ssize_t)nx_);
+        std::memcpy(out.mutable_data(), x.data(), nx_ * sizeof(float));
+        {
+            py::gil_scoped_release nogil;
+            chk(gato_plant_rk4(s_, out.mutable_data(), u_seq.data(), nsteps, f_ext6.data(), sim_dt));
+        }
+        return out;
+    }
+
     int knot_points() const { return N_; }
     int batch_size() const { return B_; }
     std::string plant() const { return plant_; }
@@ -185,6 +201,22 @@ PYBIND11_MODULE(_gato_ext, m)
 {
     m.doc() = "MI355X-native batched SQP solver (pybind11 over the C ABI of libgato_hip.so); replaces python/bindings.cu";
     m.attr("version") = gato_version();
+    // world placements (R [nq,3,3], p [nq,3], float64) of the joint frames from the library's kinematic tables -- pinocchio's
+    // data.oMi[1..nq] in MPC_GATO.transform_force_to_gato_frame (mpc_controller.py:311-338); host-only
+    m.def("fk_placements", [](const std::string& plant, farray q) {
+        const int pid = plant_id(plant);
+        int nq = 0;
+        chk(gato_dims(pid, 8, &nq, nullptr, nullptr, nullptr));
+        need(q, nq, "q");
+        std::vector<double> buf((size_t)nq * 12);
+        chk(gato_fk_placements(pid, q.data(), buf.data()));
+        py::array_t<double> R({(py::ssize_t)nq, (py::ssize_t)3, (py::ssize_t)3}), p({(py::ssize_t)nq, (py::ssize_t)3});
+        for (int k = 0; k < nq; k++) {
+            std::memcpy(R.mutable_data() + 9 * k, buf.data() + 12 * k, 9 * sizeof(double));
+            std::memcpy(p.mutable_data() + 3 * k, buf.data() + 12 * k + 9, 3 * sizeof(double));
+        }
+        return py::make_tuple(R, p);
+    });
     py::class_<PyBSQP>(m, "BSQP")
         .def(py::init<const std::string&, int, int>(), py::arg("plant"), py::arg("knot_points"), py::arg("batch_size"))
         .def(py::init<const std::string&, int, int, float, uint32_t, float, uint32_t, float, float, float, float, float, float, float, float, float, float, float>(),
@@ -204,6 +236,7 @@ PYBIND11_MODULE(_gato_ext, m)
         .def("set_rho_adaptation", &PyBSQP::set_rho_adaptation)
         .def("ee_pos", &PyBSQP::ee_pos)
         .def("select_best", &PyBSQP::select_best)
+        .def("plant_rk4", &PyBSQP::plant_rk4)
         .def_property_readonly("knot_points", &PyBSQP::knot_points)
         .def_property_readonly("batch_size", &PyBSQP::batch_size)
         .def_property_readonly("plant", &PyBSQP::plant)

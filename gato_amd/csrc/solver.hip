@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -68,6 +69,8 @@ struct GatoSolver {
     int32_t* d_sel_best;                   // [0] arg-min, [1] completion counter of the selection kernel
     float *d_ee_q, *d_ee_out;              // staging of ee_pos, grown on demand
     size_t ee_cap;
+    float* d_plant;                        // staging of gato_plant_rk4 (x | wrench | control sequence), grown on demand
+    size_t plant_cap;
     uint32_t max_iters_alloc;
     Buffers bf;
     float *d_xu_own, *d_xs_own, *d_ref_own, *d_merit_init0, *d_drho_init, *d_rho_init;
@@ -168,6 +171,8 @@ static int create_impl(GatoSolver* s, int plant, int N, int B, const GatoParams*
 #undef DA
     s->d_ee_q = s->d_ee_out = nullptr;
     s->ee_cap = 0;
+    s->d_plant = nullptr;
+    s->plant_cap = 0;
     // per-trajectory defaults (bsqp.cuh:48-58)
     s->h_rho_init.assign(B, params->rho);
     s->h_drho_init.assign(B, 1.0f);
@@ -218,6 +223,7 @@ extern "C" int gato_destroy(GatoSolver* s)
     if (s->last_stream_valid) (void)hipStreamSynchronize(s->last_stream);
     if (s->d_ee_q) (void)hipFree(s->d_ee_q);
     if (s->d_ee_out) (void)hipFree(s->d_ee_out);
+    if (s->d_plant) (void)hipFree(s->d_plant);
     for (void* p : s->allocs) (void)hipFree(p);
     for (hipEvent_t e : s->events) (void)hipEventDestroy(e);
     delete s;
@@ -751,6 +757,70 @@ extern "C" int gato_select_best(GatoSolver* s, const float* x_last, const float*
     HIPCHK(hipMemcpy(&b, s->d_sel_best, sizeof(int32_t), hipMemcpyDeviceToHost));
     *best = (int)b;
     if (errors) HIPCHK(hipMemcpy(errors, s->d_sel_err, (size_t)s->B * sizeof(float), hipMemcpyDeviceToHost));
+    return GATO_OK;
+}
+
+// The plant simulator of the MPC loop (python/bsqp/common.py:49-91 `rk4`, called 1 kHz from mpc_controller.py:199-218): nsteps RK4
+// steps of the library's own forward dynamics from x (host, [nx], updated in place) with control u_seq[step] (host, [nsteps][nu]) and a
+// constant spatial wrench [angular; linear] on the last link in its local frame.
+extern "C" int gato_plant_rk4(GatoSolver* s, float* x, const float* u_seq, int nsteps, const float* f_ext6, float sim_dt)
+{
+    if (!s || !x || !f_ext6 || nsteps < 0 || (nsteps > 0 && !u_seq)) return fail(GATO_ERR_INVALID, "bad argument");
+    if (nsteps == 0) return GATO_OK;
+    GUARD(s);
+    const size_t need = (size_t)s->nx + 6 + (size_t)nsteps * s->nu;
+    if (need > s->plant_cap) {
+        if (s->d_plant) (void)hipFree(s->d_plant);
+        s->d_plant = nullptr;
+        s->plant_cap = 0;
+        HIPCHK(hipMalloc((void**)&s->d_plant, (need + 64 * s->nu) * sizeof(float)));
+        s->plant_cap = need + 64 * s->nu;
+    }
+    float *d_x = s->d_plant, *d_f = d_x + s->nx, *d_u = d_f + 6;
+    std::vector<float> h(need);
+    memcpy(h.data(), x, s->nx * sizeof(float));
+    memcpy(h.data() + s->nx, f_ext6, 6 * sizeof(float));
+    memcpy(h.data() + s->nx + 6, u_seq, (size_t)nsteps * s->nu * sizeof(float));
+    HIPCHK(hipMemcpy(d_x, h.data(), need * sizeof(float), hipMemcpyHostToDevice));
+    if (s->plant == GATO_PLANT_INDY7) hipLaunchKernelGGL((plant_rk4_kernel<Indy7>), dim3(1), dim3(64), 0, nullptr, d_x, d_u, d_f, nsteps, sim_dt, 1);
+    else hipLaunchKernelGGL((plant_rk4_kernel<Iiwa14>), dim3(1), dim3(64), 0, nullptr, d_x, d_u, d_f, nsteps, sim_dt, 1);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(x, d_x, s->nx * sizeof(float), hipMemcpyDeviceToHost));
+    return GATO_OK;
+}
+
+// World placements of the joint frames (pinocchio's data.oMi[1..nq], which MPC_GATO.transform_force_to_gato_frame reads,
+// mpc_controller.py:311-338) from the library's own kinematic tables: oMi_k = oMi_{k-1} [R0_k Rz(q_k) | r_k], R0_k = E0_k^T.
+// Host code, float64, no device: out[k] = {R row-major (9), p (3)}.
+template<class M> static void fk_placements(const float* q, double* out)
+{
+    double R[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}}, p[3] = {0, 0, 0};
+    for (int k = 0; k < M::NQ; k++) {
+        const double c = cos((double)q[k]), sn = sin((double)q[k]);
+        double L[3][3], Rn[3][3], pn[3];  // L = E0^T Rz(q)
+        for (int i = 0; i < 3; i++) {
+            const double a = M::E0[k][0][i], b = M::E0[k][1][i], cc = M::E0[k][2][i];  // row i of E0^T
+            L[i][0] = a * c + b * sn;
+            L[i][1] = -a * sn + b * c;
+            L[i][2] = cc;
+        }
+        for (int i = 0; i < 3; i++) {
+            pn[i] = p[i] + R[i][0] * M::R[k][0] + R[i][1] * M::R[k][1] + R[i][2] * M::R[k][2];
+            for (int j = 0; j < 3; j++) Rn[i][j] = R[i][0] * L[0][j] + R[i][1] * L[1][j] + R[i][2] * L[2][j];
+        }
+        for (int i = 0; i < 3; i++) {
+            p[i] = pn[i];
+            for (int j = 0; j < 3; j++) { R[i][j] = Rn[i][j]; out[12 * k + 3 * i + j] = Rn[i][j]; }
+            out[12 * k + 9 + i] = pn[i];
+        }
+    }
+}
+extern "C" int gato_fk_placements(int plant, const float* q, double* out)
+{
+    if (!q || !out) return fail(GATO_ERR_INVALID, "null argument");
+    if (plant == GATO_PLANT_INDY7) fk_placements<Indy7>(q, out);
+    else if (plant == GATO_PLANT_IIWA14) fk_placements<Iiwa14>(q, out);
+    else return fail(GATO_ERR_INVALID, "unknown plant");
     return GATO_OK;
 }
 

@@ -118,6 +118,15 @@ int gato_select_best(GatoSolver* s, const float* x_last, const float* u_last, co
 int gato_select_best_device(GatoSolver* s, const float* d_x_last, const float* d_u_last, const float* d_x_meas, float dt, int32_t* d_best,
                             float* d_errors, void* stream);
 
+/* The plant of the closed MPC loop (python/bsqp/common.py:49-91 `rk4` over pinocchio's aba, stepped at 1 kHz by
+ * mpc_controller.py:199-218), on the library's own forward dynamics: nsteps RK4 steps of size sim_dt from x ([nx], host, updated in
+ * place) with control u_seq[step] ([nsteps][nu], host) under the constant spatial wrench f_ext6 = [angular; linear] acting on the
+ * last link, expressed in that link's frame. */
+int gato_plant_rk4(GatoSolver* s, float* x, const float* u_seq, int nsteps, const float* f_ext6, float sim_dt);
+/* World placements of the nq joint frames (pinocchio's data.oMi[1..nq] in mpc_controller.py:311-338) from the library's own
+ * kinematic tables: out[k] = {R row-major (9 doubles), p (3 doubles)}.  Host-only, no device needed. */
+int gato_fk_placements(int plant, const float* q, double* out);
+
 /* End-effector positions [n][3] of n joint configurations [n][nq] (host arrays): what interface.BSQP.ee_pos obtains from
  * pinocchio in the reference (python/bsqp/interface.py:212-214), computed with the solver's own kinematics. */
 int gato_ee_pos(GatoSolver* s, const float* q, int n, float* out);

@@ -1,0 +1,144 @@
+"""The callers either side of the hot path: plant simulator, force transformation, hypothesis selection and the
+closed MPC loop of python/bsqp/mpc_controller.py on the library's own rigid-body code (no pinocchio)."""
+import numpy as np
+import pytest
+
+from gato_amd.bsqp.common import figure8
+from gato_amd.bsqp.config import DEFAULT_SOLVER_PARAMS, FIG8_DEFAULT_PARAMS, INDY7_START_CONFIGS
+
+
+def _rot(axis, ang):
+    axis = axis / np.linalg.norm(axis)
+    K = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+    return np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * K @ K
+
+
+@pytest.mark.parametrize("plant", ["indy7", "iiwa14"])
+def test_fk_placements_are_a_consistent_revolute_chain(plant):
+    """gato_fk_placements (host code): orthonormal frames, the last origin is the end effector of the oracle's kinematics, and
+    turning joint k moves every later origin on a circle about joint k's own z axis (what data.oMi means in pinocchio)"""
+    from gato_amd._lib import fk_placements
+    from oracle import oracle as O
+    nq = 6 if plant == "indy7" else 7
+    rng = np.random.default_rng(2)
+    q = rng.uniform(-1.5, 1.5, nq).astype(np.float32)
+    R, p = fk_placements(plant, q)
+    for k in range(nq):
+        assert np.abs(R[k] @ R[k].T - np.eye(3)).max() < 1e-12 and abs(np.linalg.det(R[k]) - 1) < 1e-12
+    np.testing.assert_allclose(p[-1], O.ee(plant, q)[0], atol=2e-6)
+    for k in range(nq - 1):
+        d = 0.37
+        q2 = q.copy(); q2[k] += d
+        R2, p2 = fk_placements(plant, q2)
+        np.testing.assert_allclose(p2[:k + 1], p[:k + 1], atol=1e-6)                       # joints up to k do not move
+        rot = _rot(R[k][:, 2], float(q2[k]) - float(q[k]))
+        for j in range(k + 1, nq):
+            np.testing.assert_allclose(p2[j] - p[k], rot @ (p[j] - p[k]), atol=2e-6)
+            np.testing.assert_allclose(R2[j], rot @ R[j], atol=2e-6)
+
+
+def test_transform_force_to_gato_frame_formula():
+    """MPC_GATO.transform_force_to_gato_frame (mpc_controller.py:311-338) = two SE3.actInv's; checked against homogeneous
+    adjoint algebra written independently (wrench row-vector convention)"""
+    from gato_amd._lib import fk_placements
+    from gato_amd.bsqp.mpc_controller import MPC_GATO
+    q = np.array([0.3, -0.7, 1.1, 0.2, -0.4, 0.9])
+    f = np.array([3.0, -2.0, 5.0, 0.4, 0.1, -0.3])
+    R, p = fk_placements("indy7", q.astype(np.float32))
+
+    def wrench_in_frame(Rf, pf, lin, ang):
+        # moment about the frame's origin, both rotated into the frame
+        return Rf.T @ lin, Rf.T @ (ang + np.cross(lin, pf))
+    lin, ang = wrench_in_frame(R[-1], p[-1], f[:3], f[3:])
+    Rr, pr = R[-2].T @ R[-1], R[-2].T @ (p[-1] - p[-2])
+    lin, ang = wrench_in_frame(Rr, pr, lin, ang)
+    got = MPC_GATO.transform_force_to_gato_frame(type("S", (), {"plant_type": "indy7", "nq": 6})(), q, f)
+    np.testing.assert_allclose(got, np.concatenate([lin, ang]), atol=1e-12)
+    assert abs(np.linalg.norm(got[:3]) - np.linalg.norm(f[:3])) < 1e-12                     # the force part is only rotated
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("plant", ["indy7", "iiwa14"])
+def test_plant_rk4_against_numpy_rk4_over_the_oracle_dynamics(plant):
+    """gato_plant_rk4 (the MPC loop's plant, common.py:49-91 semantics) vs the same RK4 scheme in numpy over the oracle's forward dynamics"""
+    from gato_amd._lib import NativeSolver
+    from oracle import oracle as O
+    s = NativeSolver(plant, 8, 1)
+    nq = s.nq
+    rng = np.random.default_rng(4)
+    q, v = rng.uniform(-0.8, 0.8, nq), rng.uniform(-0.5, 0.5, nq)
+    fe = rng.normal(0, 4.0, 6)
+    useq = rng.uniform(-6, 6, (7, nq))
+    h = 0.001
+    x = s.plant_rk4(np.concatenate([q, v]), useq, fe, h)
+    for u in useq:
+        fd = lambda qq, vv: O.fd(plant, qq, vv, u, fe).astype(np.float64)  # noqa: E731
+        k1v = fd(q, v)
+        k2q = v + k1v * h / 2; k2v = fd(q + v * h / 2, k2q)
+        k3q = v + k2v * h / 2; k3v = fd(q + k2q * h / 2, k3q)
+        k4q = v + k3v * h; k4v = fd(q + k3q * h, k4q)
+        q = q + h * (v + 2 * k2q + 2 * k3q + k4q) / 6
+        v = v + (h / 6) * (k1v + 2 * k2v + 2 * k3v + k4v)
+    np.testing.assert_allclose(x, np.concatenate([q, v]), rtol=2e-5, atol=2e-6)
+
+
+def _x_start():
+    return np.concatenate([INDY7_START_CONFIGS["ready"], np.zeros(6)])
+
+
+@pytest.mark.gpu
+def test_closed_loop_fig8_single_trajectory():
+    """run_mpc_fig8 (mpc_controller.py:136-277), B = 1, one SQP iteration per step, a fixed 2 ms per solve: the arm converges onto the
+    figure-8 and follows it; the run is reproducible bit for bit"""
+    from gato_amd.bsqp.mpc_controller import MPC_GATO
+    fig8 = figure8(0.01, **FIG8_DEFAULT_PARAMS)
+    runs = []
+    for _ in range(2):
+        mpc = MPC_GATO(None, None, N=32, dt=0.01, batch_size=1, plant_type="indy7", track_full_stats=True)
+        _, st = mpc.run_mpc_fig8(_x_start(), fig8, sim_dt=0.001, sim_time=1.0, solve_time_override=0.002, verbose=False)
+        runs.append(st)
+    a, b = runs
+    assert len(a["timestamps"]) >= 400 and np.all(np.isfinite(a["joint_positions"]))
+    for k in ("goal_distances", "joint_positions", "joint_velocities", "ee_actual"):
+        np.testing.assert_array_equal(a[k], b[k])
+    d = a["goal_distances"]
+    assert d[-100:].mean() < 0.5 * d[:20].mean() and d[-100:].max() < 0.05, (d[:20].mean(), d[-100:].mean(), d[-100:].max())
+    assert np.all(a["solve_times"] > 0) and np.all(a["sqp_iters"] == DEFAULT_SOLVER_PARAMS["max_sqp_iters"])
+    assert set(a) == {"timestamps", "solve_times", "goal_distances", "ee_actual", "joint_positions", "joint_velocities", "sqp_iters"}
+
+
+@pytest.mark.gpu
+def test_closed_loop_with_force_hypotheses():
+    """A constant 15 N disturbance on the last link, B = 16 force hypotheses (ForceEstimator + transform + device-side selection):
+    the batched controller tracks better than the single-hypothesis controller that knows nothing about the force, and its estimate
+    moves towards the disturbance"""
+    from gato_amd.bsqp.mpc_controller import MPC_GATO
+    fig8 = figure8(0.01, **FIG8_DEFAULT_PARAMS)
+    f = np.array([0.0, 0.0, -15.0, 0.0, 0.0, 0.0])
+    res = {}
+    for B in (1, 16):
+        np.random.seed(0)
+        mpc = MPC_GATO(None, None, N=32, dt=0.01, batch_size=B, constant_f_ext=f, plant_type="indy7")
+        _, st = mpc.run_mpc_fig8(_x_start(), fig8, sim_dt=0.001, sim_time=1.2, solve_time_override=0.002, verbose=False)
+        res[B] = (st, mpc)
+    d1, d16 = res[1][0]["goal_distances"], res[16][0]["goal_distances"]
+    assert np.all(np.isfinite(d16)) and d16[-200:].mean() < d1[-200:].mean(), (d1[-200:].mean(), d16[-200:].mean())
+    est = res[16][1].force_estimator.get_stats()
+    assert np.linalg.norm(est["smoothed_estimate"][:3]) > 1.0
+
+
+@pytest.mark.gpu
+def test_closed_loop_goals():
+    """run_mpc_goals (mpc_controller.py:361-599): two reachable goals, statistics keys of the reference"""
+    from gato_amd.bsqp.config import PICKPLACE_SOLVER_PARAMS
+    from gato_amd.bsqp.mpc_controller import MPC_GATO
+    mpc = MPC_GATO(None, None, N=16, dt=0.03, batch_size=1, plant_type="indy7", solver_params=PICKPLACE_SOLVER_PARAMS, track_full_stats=True)
+    e0 = mpc.solver.ee_pos(INDY7_START_CONFIGS["ready"])
+    goals = [e0 + np.array([0.10, 0.05, -0.10]), e0 + np.array([-0.05, 0.10, 0.05])]
+    _, st = mpc.run_mpc_goals(_x_start(), goals, sim_dt=0.001, goal_timeout=4.0, solve_time_override=0.004, verbose=False)
+    assert st["goal_outcomes"] == ["reached", "reached"], (st["goal_outcomes"], st["goal_distances"][-5:])
+    assert st["time_to_all_reached"] is not None and st["time_to_all_reached"] < 8.0
+    assert {"timestamps", "solve_times", "goal_distances", "ee_actual", "joint_positions", "joint_velocities", "best_trajectory_id", "goal_outcomes",
+            "goal_reached_times", "time_to_all_reached", "sqp_iters", "pcg_iters"} == set(st)
+    with pytest.raises(NotImplementedError):
+        MPC_GATO(None, None, pendulum_config={"mass": 15.0})

@@ -44,6 +44,43 @@ def reference_python():
     print("wrote reference_python.npz")
 
 
+def reference_force_estimator():
+    """ForceEstimator of the reference (examples/force_estimator.py, pure numpy) driven through a fixed script: batches at reset, after
+    every update and after a reset, with numpy's global stream seeded -> tests/golden/reference_force_estimator.npz"""
+    ref = "/root/reference/examples"
+    if not os.path.isdir(ref):
+        print("reference not present; skipping reference_force_estimator.npz")
+        return
+    sys.path.insert(0, ref)
+    import importlib
+    fe = importlib.import_module("force_estimator")
+    sys.path.remove(ref)
+    out = {}
+    for B in (4, 16, 128):
+        np.random.seed(1234 + B)
+        est = fe.ForceEstimator(batch_size=B, initial_radius=5.0, min_radius=2.0, max_radius=20.0, smoothing_factor=0.5)  # mpc_controller.py:126-132
+        rng = np.random.default_rng(B)
+        batches, radii, script = [est.generate_batch()], [est.radius], []
+        for step in range(12):
+            errors = rng.uniform(0.0, 1.0, B) * (0.02 if step in (6, 7, 8, 9, 10) else 1.0)
+            best = int(np.argmin(errors)) if step % 3 else int(rng.integers(0, B))
+            est.update(best, errors, alpha=0.6, beta=0.5)                                                                  # mpc_controller.py:307
+            script.append(np.concatenate([[best], errors]))
+            batches.append(est.generate_batch())
+            radii.append(est.radius)
+        st = est.get_stats()
+        est.reset()
+        out["B%d_batches" % B] = np.stack(batches)
+        out["B%d_radius" % B] = np.array(radii, np.float64)
+        out["B%d_script" % B] = np.stack(script)
+        out["B%d_confidence" % B] = np.float64(st["confidence"])
+        out["B%d_after_reset" % B] = est.generate_batch()
+        out["B%d_sphere" % B] = est.sphere_dirs
+    np.savez_compressed(os.path.join(GOLD, "reference_force_estimator.npz"), **out)
+    del sys.modules["force_estimator"]
+    print("wrote reference_force_estimator.npz")
+
+
 def oracle_cases():
     from gato_amd.bsqp.config import DEFAULT_SOLVER_PARAMS
     from gato_amd.bsqp.workloads import fig8_problem
@@ -71,4 +108,6 @@ def oracle_cases():
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     reference_python()
-    oracle_cases()
+    reference_force_estimator()
+    if "--no-oracle" not in sys.argv:
+        oracle_cases()

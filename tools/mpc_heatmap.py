@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""The reference's published workload, measured directly: mean `sqp_time_us` per MPC step of the figure-8 tracking loop
+(examples/benchmark_fig8.py:81-90 -> MPC_GATO.run_mpc_fig8, DEFAULT_SOLVER_PARAMS: ONE SQP iteration per solve) for a row of the
+solve-time heat-map (plots/gato_solve_time_heatmap.png).  Runs on the MI355X box.
+
+    python tools/mpc_heatmap.py --knots 32 --out gpurun_out/mpc_heatmap_N32.json
+"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+# plots/gato_solve_time_heatmap.png as transcribed in BASELINE.md (ms, unstated NVIDIA GPU), batch 1..512
+PUBLISHED = {8: [0.09, 0.10, 0.10, 0.10, 0.10, 0.10, 0.11, 0.15, 0.29, 0.58], 16: [0.10, 0.10, 0.10, 0.10, 0.10, 0.12, 0.16, 0.31, 0.63, 1.37],
+             32: [0.10, 0.10, 0.10, 0.11, 0.12, 0.17, 0.33, 0.65, 1.41, 2.84], 64: [0.12, 0.12, 0.12, 0.14, 0.19, 0.37, 0.75, 1.48, 2.95, 7.76],
+             128: [0.16, 0.17, 0.19, 0.25, 0.47, 0.93, 1.71, 3.15, 9.98, 19.98]}
+BATCHES = [1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--knots", type=int, nargs="+", default=[32])
+    ap.add_argument("--sim-time", type=float, default=0.6)
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "mpc_heatmap.json"))
+    a = ap.parse_args()
+    from gato_amd.bsqp.common import figure8
+    from gato_amd.bsqp.config import FIG8_DEFAULT_PARAMS, INDY7_START_CONFIGS
+    from gato_amd.bsqp.mpc_controller import MPC_GATO
+    fig8 = figure8(0.01, **FIG8_DEFAULT_PARAMS)
+    x0 = np.concatenate([INDY7_START_CONFIGS["ready"], np.zeros(6)])
+    rows = []
+    for N in a.knots:
+        for i, B in enumerate(BATCHES):
+            np.random.seed(0)
+            mpc = MPC_GATO(None, None, N=N, dt=0.01, batch_size=B, plant_type="indy7")
+            # B in {2} cannot build the force estimator (it needs > 3 hypotheses, force_estimator.py:8): like the reference's benchmark
+            # (benchmark_fig8.py passes no disturbance) the batch then carries identical zero-force hypotheses
+            _, st = mpc.run_mpc_fig8(x0, fig8, sim_dt=0.001, sim_time=a.sim_time, solve_time_override=0.002, verbose=False)
+            t = np.asarray(st["solve_times"])
+            pub = PUBLISHED.get(N, [None] * 10)
+            r = dict(knots=N, batch=B, steps=int(t.size), mean_ms=float(t.mean()), median_ms=float(np.median(t)), p95_ms=float(np.percentile(t, 95)),
+                     mean_goal_dist=float(np.mean(st["goal_distances"])), published_ms=pub[i] if i < len(pub) else None)
+            rows.append(r)
+            print(json.dumps(r), flush=True)
+    os.makedirs(os.path.dirname(a.out), exist_ok=True)
+    json.dump(rows, open(a.out, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
