@@ -54,7 +54,9 @@ class MPC_GATO:
         self.actual_f_ext = np.concatenate([f[3:], f[:3]]).astype(np.float32)
 
     def setup_force_estimator(self):
-        if self.batch_size > 1:
+        # the estimator needs > 3 hypotheses (force_estimator.py:8); the reference's benchmark runs batch 2 without one (its import of
+        # examples/force_estimator.py is optional, mpc_controller.py:10-14): smaller batches carry identical zero-force hypotheses
+        if self.batch_size > 3:
             self.force_estimator = ForceEstimator(batch_size=self.batch_size, initial_radius=5.0, min_radius=2.0, max_radius=20.0, smoothing_factor=0.5)
         else:
             self.force_estimator = None
