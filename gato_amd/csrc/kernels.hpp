@@ -321,7 +321,7 @@ GATO_DEV float merit_term(const Buffers& bf, const Costs& cw, int N, int b, int 
 
 template<class M, int NA>
 __global__ __launch_bounds__(256) void merit_kernel(Buffers bf, int N, int B, float dt, int use_dz, int sqp_iter, float thresh,
-                                                    float* __restrict__ out)
+                                                    float* __restrict__ out, float* __restrict__ out2, float4* __restrict__ zero4, uint32_t zero_n4)
 {
     constexpr int NQ = M::NQ, NX = 2 * NQ, NU = NQ, KS = NX + NU;
     __shared__ float part[4];
@@ -330,6 +330,9 @@ __global__ __launch_bounds__(256) void merit_kernel(Buffers bf, int N, int B, fl
         if ((float)bf.num_solved[sqp_iter] >= thresh) return;  // loop breaks before the line search (bsqp.cuh:165)
     }
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    // the first launch of a solve also clears what bsqp.cuh:112-114 memsets (dz, PCG counts, convergence flags) and the device-side
+    // loop control: nothing reads them before the next launch, and a fill launch of its own costs 2-4 us per solve
+    for (uint32_t i = g; i < zero_n4; i += gridDim.x * blockDim.x) zero4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     const int k = g % N, ai = (g / N) % NA;
     int b = g / (N * NA);
     const bool live = b < B;
@@ -337,7 +340,10 @@ __global__ __launch_bounds__(256) void merit_kernel(Buffers bf, int N, int B, fl
     const float alpha = (float)(1.0 / (double)(1 << ai));
     float m = merit_term<M>(bf, load_costs(bf, b), N, b, k, alpha, use_dz, bf.dz + (size_t)b * (KS * N - NU), dt);
     m = seg_sum(m, N, part);
-    if (live && k == 0) out[b * NA + ai] = m;
+    if (live && k == 0) {
+        out[b * NA + ai] = m;
+        if (NA == 1 && out2) out2[b] = m;  // merit_initial0 (bsqp.cuh:116-118) without a device-to-device copy
+    }
 }
 
 // =========================================================================================================================
@@ -1844,7 +1850,9 @@ __global__ __launch_bounds__(256) void dz_kernel(Buffers bf, int N, int B, float
 // line search + trajectory update + rho adaptation (line_search.cuh:13-98): one workgroup per trajectory
 // =========================================================================================================================
 // the line search of trajectory b by its workgroup: mer = the 8 merits, dz = the step (global or LDS)
-GATO_DEV void line_search_block(const Buffers& bf, int b, int B, int traj, const float* mer, const float* dz, int adapt_rho, int sqp_iter)
+// `drho_reset` (non-null in the LAST iteration of a solve): drho goes back to its default once the search has used it (bsqp.cuh:189)
+GATO_DEV void line_search_block(const Buffers& bf, int b, int B, int traj, const float* mer, const float* dz, int adapt_rho, int sqp_iter,
+                                const float* drho_reset)
 {
     float best = 1e38f;
     uint32_t idx = 0;
@@ -1877,6 +1885,7 @@ GATO_DEV void line_search_block(const Buffers& bf, int b, int B, int traj, const
         bf.st_step[(size_t)sqp_iter * B + b] = step;
         bf.st_min_merit[(size_t)sqp_iter * B + b] = success ? best : cur;
         if (b == 0) bf.ctrl->ls_done = sqp_iter + 1;
+        if (drho_reset) bf.drho[b] = drho_reset[b];
     }
     if (success) {
         const float step = (float)(1.0 / (double)(1 << idx));
@@ -1884,22 +1893,27 @@ GATO_DEV void line_search_block(const Buffers& bf, int b, int B, int traj, const
         for (int i = threadIdx.x; i < traj; i += blockDim.x) x[i] += step * dz[i];
     }
 }
-__global__ __launch_bounds__(128) void line_search_kernel(Buffers bf, int traj, int B, int adapt_rho, int sqp_iter, float thresh)
+// drho_init: the per-trajectory default drho; the solve's exit paths -- the last iteration's search, or the solve_ratio break before
+// a search -- put drho back to it (bsqp.cuh:189) so that no copy has to follow the loop
+__global__ __launch_bounds__(128) void line_search_kernel(Buffers bf, int traj, int B, int adapt_rho, int sqp_iter, float thresh,
+                                                          const float* __restrict__ drho_init, int last_iter)
 {
     if (bf.ctrl->done) return;
+    const int b = blockIdx.x;
     if ((float)bf.num_solved[sqp_iter] >= thresh) {
         if (blockIdx.x == 0 && threadIdx.x == 0) bf.ctrl->done = 1;  // every block takes the same branch; later kernels see done
+        if (threadIdx.x == 0) bf.drho[b] = drho_init[b];
         return;
     }
-    const int b = blockIdx.x;
-    line_search_block(bf, b, B, traj, bf.merit + (size_t)b * NUM_ALPHAS, bf.dz + (size_t)b * traj, adapt_rho, sqp_iter);
+    line_search_block(bf, b, B, traj, bf.merit + (size_t)b * NUM_ALPHAS, bf.dz + (size_t)b * traj, adapt_rho, sqp_iter, last_iter ? drho_init : nullptr);
 }
 
 // dz + merit at the 8 step sizes + line search in ONE launch, a workgroup of 8 N lanes per trajectory (N <= 64): the step never
 // leaves the CU between the three (LDS), two launches and their cache write-back / invalidate are gone.  Lane t < N forms dz_t, then
 // lane t is (alpha index t / N, knot t % N) of the merit evaluation, then all lanes apply the chosen step.
 template<class M>
-__global__ __launch_bounds__(512) void step_kernel(Buffers bf, int N, int B, float dt, int sqp_iter, float thresh, int adapt_rho)
+__global__ __launch_bounds__(512) void step_kernel(Buffers bf, int N, int B, float dt, int sqp_iter, float thresh, int adapt_rho,
+                                                   const float* __restrict__ drho_init, int last_iter)
 {
     constexpr int NQ = M::NQ, NX = 2 * NQ, NU = NQ, KS = NX + NU;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1914,7 +1928,10 @@ __global__ __launch_bounds__(512) void step_kernel(Buffers bf, int N, int B, flo
     else if (t < 2 * N) dz_knot<M, 2>(bf, N, b, t - N, dt, dzs);  // control rows
     // The loop breaks before the line search (bsqp.cuh:165); every workgroup takes the same branch.  `done` is raised by the NEXT
     // launch (kkt_kernel): set here it could stop a workgroup of this very launch before its dz.
-    if ((float)bf.num_solved[sqp_iter] >= thresh) return;
+    if ((float)bf.num_solved[sqp_iter] >= thresh) {
+        if (t == 0) bf.drho[b] = drho_init[b];  // the solve ends here (bsqp.cuh:165,189)
+        return;
+    }
     __syncthreads();
     {
         const int k = t % N, ai = t / N;
@@ -1927,7 +1944,7 @@ __global__ __launch_bounds__(512) void step_kernel(Buffers bf, int N, int B, flo
         }
     }
     __syncthreads();
-    line_search_block(bf, b, B, traj, mer, dzs, adapt_rho, sqp_iter);
+    line_search_block(bf, b, B, traj, mer, dzs, adapt_rho, sqp_iter, last_iter ? drho_init : nullptr);
 }
 
 // =========================================================================================================================

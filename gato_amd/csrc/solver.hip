@@ -233,15 +233,18 @@ extern "C" int gato_destroy(GatoSolver* s)
 // ---- launches ---------------------------------------------------------------------------------------------------------
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
-template<class M> static void launch_merit(GatoSolver* s, hipStream_t st, int na, float dt, int use_dz, int sqp_iter, float* out)
+// out2 / zero: only for the first launch of a solve (merit of the initial iterate): second copy of the merits, slab to clear
+template<class M> static void launch_merit(GatoSolver* s, hipStream_t st, int na, float dt, int use_dz, int sqp_iter, float* out, float* out2 = nullptr,
+                                           float* zero = nullptr, size_t zero_words = 0)
 {
     const float thresh = (float)s->B * s->p.solve_ratio;
     const long n = (long)s->B * na * s->N;
     if (na == 1)
-        hipLaunchKernelGGL((merit_kernel<M, 1>), dim3(cdiv(n, 256)), dim3(256), 0, st, s->bf, s->N, s->B, dt, use_dz, sqp_iter, thresh, out);
+        hipLaunchKernelGGL((merit_kernel<M, 1>), dim3(cdiv(n, 256)), dim3(256), 0, st, s->bf, s->N, s->B, dt, use_dz, sqp_iter, thresh, out, out2,
+                           reinterpret_cast<float4*>(zero), (uint32_t)(zero_words / 4));
     else
         hipLaunchKernelGGL((merit_kernel<M, NUM_ALPHAS>), dim3(cdiv(n, 256)), dim3(256), 0, st, s->bf, s->N, s->B, dt, use_dz, sqp_iter,
-                           thresh, out);
+                           thresh, out, (float*)nullptr, (float4*)nullptr, 0u);
 }
 template<class M> static void launch_kkt(GatoSolver* s, hipStream_t st, float dt, int sqp_iter, int row0 = 0)
 {
@@ -423,17 +426,19 @@ static bool step_fused(const GatoSolver* s)
 {
     return s->fuse_step && NUM_ALPHAS * s->N <= 512 && s->N <= 64;
 }
-template<class M> static void launch_step(GatoSolver* s, hipStream_t st, float dt, int sqp_iter)
+// last: this is the final iteration of the solve -- the line search also puts drho back to its default (bsqp.cuh:189)
+template<class M> static void launch_step(GatoSolver* s, hipStream_t st, float dt, int sqp_iter, int last)
 {
     const float thresh = (float)s->B * s->p.solve_ratio;
     const size_t lds = (size_t)(((s->traj + 3) & ~3) + 16) * sizeof(float);
     hipLaunchKernelGGL((step_kernel<M>), dim3(s->B), dim3(NUM_ALPHAS * s->N), lds, st, s->bf, s->N, s->B, dt, sqp_iter, thresh,
-                       s->adapt_rho);
+                       s->adapt_rho, (const float*)s->d_drho_init, last);
 }
-static void launch_ls(GatoSolver* s, hipStream_t st, int sqp_iter)
+static void launch_ls(GatoSolver* s, hipStream_t st, int sqp_iter, int last)
 {
     const float thresh = (float)s->B * s->p.solve_ratio;
-    hipLaunchKernelGGL(line_search_kernel, dim3(s->B), dim3(128), 0, st, s->bf, s->traj, s->B, s->adapt_rho, sqp_iter, thresh);
+    hipLaunchKernelGGL(line_search_kernel, dim3(s->B), dim3(128), 0, st, s->bf, s->traj, s->B, s->adapt_rho, sqp_iter, thresh,
+                       (const float*)s->d_drho_init, last);
 }
 
 static void mark(GatoSolver* s, hipStream_t st, int stage, size_t& ei)
@@ -458,11 +463,10 @@ template<class M> static int solve_impl(GatoSolver* s, float* d_xu, float dt, co
     s->last_stream = st;
     s->last_stream_valid = true;
     size_t ei = 0;
-    // bsqp.cuh:112-114 (+ the device-side loop control)
-    HIPCHK(hipMemsetAsync(s->zero_slab, 0, s->zero_words * sizeof(float), st));  // dz, pcg_iters, converged, ctrl, num_solved
     mark(s, st, -1, ei);
-    launch_merit<M>(s, st, 1, dt, 0, -1, bf.merit_cur);  // bsqp.cuh:116-118
-    HIPCHK(hipMemcpyAsync(s->d_merit_init0, bf.merit_cur, B * sizeof(float), hipMemcpyDeviceToDevice, st));
+    // bsqp.cuh:112-118 in ONE launch: the merit of the initial iterate (kept twice: running merit and merit_initial0) and the clearing of
+    // dz, pcg_iters, converged, ctrl, num_solved (the slab is a multiple of 64 words)
+    launch_merit<M>(s, st, 1, dt, 0, -1, bf.merit_cur, s->d_merit_init0, s->zero_slab, s->zero_words);
     mark(s, st, ST_MERIT, ei);
     const uint32_t iters = s->p.max_sqp_iters <= s->max_iters_alloc ? s->p.max_sqp_iters : s->max_iters_alloc;
     for (uint32_t it = 0; it < iters; it++) {
@@ -478,21 +482,23 @@ template<class M> static int solve_impl(GatoSolver* s, float* d_xu, float dt, co
         }
         mark(s, st, ST_PCG, ei);
         if (step_fused(s)) {
-            launch_step<M>(s, st, dt, (int)it);
+            launch_step<M>(s, st, dt, (int)it, it + 1 == iters);
             mark(s, st, ST_MERIT, ei);
         } else {
             launch_dz<M>(s, st, dt, (int)it);
             mark(s, st, ST_DZ, ei);
             launch_merit<M>(s, st, NUM_ALPHAS, dt, 1, (int)it, bf.merit);
             mark(s, st, ST_MERIT, ei);
-            launch_ls(s, st, (int)it);
+            launch_ls(s, st, (int)it, it + 1 == iters);
             mark(s, st, ST_LS, ei);
         }
     }
     // The merit of the returned xu (bsqp.cuh:180-182) needs no launch: merit_cur already holds it -- the line search stores the merit
     // of the step it accepts, evaluated at fma(alpha, dz, xu), which is exactly what it then writes to xu
     // (tests/test_gpu_parity.py::test_final_merit_is_the_merit_of_the_returned_iterates recomputes it).
-    HIPCHK(hipMemcpyAsync(bf.drho, s->d_drho_init, B * sizeof(float), hipMemcpyDeviceToDevice, st));  // bsqp.cuh:189; rho is NOT reset
+    // bsqp.cuh:189 (drho back to its default; rho is NOT reset) is done by the kernel that ends the loop -- the last line search or the
+    // solve_ratio break -- so only a solve without iterations needs the copy
+    if (iters == 0) HIPCHK(hipMemcpyAsync(bf.drho, s->d_drho_init, B * sizeof(float), hipMemcpyDeviceToDevice, st));
     HIPCHK(hipGetLastError());
     return GATO_OK;
 }
@@ -922,7 +928,7 @@ template<class M> static int stage_impl(GatoSolver* s, int stage, float dt, floa
         case 2: launch_schur<M>(s, st, dt, true); break;   // stage tests read the complete P^-1
         case 3: launch_pcg<M>(s, st, 0, 1); break;
         case 4: launch_dz<M>(s, st, dt, 0); break;
-        case 5: launch_ls(s, st, 0); break;
+        case 5: launch_ls(s, st, 0, 0); break;
         case 6: launch_merit<M>(s, st, 1, dt, 0, -1, bf.merit_cur); break;
         default: return fail(GATO_ERR_INVALID, "unknown stage");
     }
