@@ -23,6 +23,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "rbd.hpp"
 
 namespace gato {
@@ -1732,6 +1734,212 @@ __global__ __launch_bounds__(MAXT) void pcgc_kernel(Buffers bf, int N, int B, ui
                 for (int u = 0; u < RPT; u++) pv[u] = zv[u] + beta * pv[u];
             }
             if (have) store_vec<RPT, RPT>(lam + NX + rr, xv);
+        }
+    }
+    if (threadIdx.x == 0) {
+        bf.pcg_iters[b] = iters;
+        bf.st_pcg_iters[(size_t)sqp_iter * B + b] = (int32_t)iters;
+        int conv = skip ? 1 : 0;
+        if (iters == 0) { conv = 1; bf.converged[b] = 1; }  // bsqp.cuh:153-156 (kkt_tol is unused there)
+        if (conv) atomicAdd(&bf.num_solved[sqp_iter], 1u);
+    }
+}
+
+// ---- PCG, register-resident in SYMMETRIC HALF STORAGE (long horizons: iiwa14 N = 128 is 602 KB of S and P^-1 per trajectory) ------
+// S and P^-1 are symmetric block-tridiagonal with right_k = left_{k+1}^T EXACTLY (schur1 stores phi^T by transposition,
+// schur_linsys.cuh:130-146; schur2 writes -res and -res^T from one `res`, :243-258), so the right blocks need no storage: a row's
+// product is  left_k v_{k-1} + main_k v_k + (left_{k+1}^T v_{k+1}),  and the last term is formed by the threads that hold left_{k+1}
+// as a TRANSPOSED accumulate.  A trajectory then needs 2 x N nx x 2 nx floats = 401 KB (iiwa14 N = 128): one CU's register file holds
+// it (512 KB), one workgroup per trajectory, B = 256 = one trajectory per CU -- nothing is re-read from L2 / MALL during the
+// iteration (the streaming kernel moved 602 KB per PCG iteration and trajectory and was bound by exactly that: 2.5 ms per launch).
+//
+// Workgroup = 4 N threads in two ROLES, split by wavefront (role = t >= 2N), u = t mod 2N, block row k = u / 2, row half h = u % 2:
+//   left role : rows k nx + h nx/2 .. of left_k (S and P^-1): the row dot with v_{k-1} AND the transposed accumulate left_k^T v_k;
+//   main role : the same rows of main_k: the row dot with v_k; owns the vector entries x, r, p of its rows and does the PCG scalar work.
+// Per matrix-vector product: vector -> LDS | barrier | both roles work, the left role leaves its row partials and transposed partials in
+// LDS | barrier | the main role adds  main + left + (two halves of the transposed partial of block k+1).  Four rows of every thread's
+// P^-1 block live in LDS (float4 [nx][T], conflict-free) to stay under 256 registers.  Sums associate as (main + left) + t0 + t1; the
+// reference sums a row's 3 nx terms in sequence (linalg.cuh:174-260) -- the same fp32 freedom the other PCG kernels take (even / odd
+// pairs).  Needs the COMPLETE P^-1 in global memory (schur2_kernel) and N >= 16 (whole wavefronts).
+// One thread's HR x NX block times the window w (row dots) and -- TR -- its transpose times the
+// thread's own HR vector entries vo (tp[j] = sum_i Mt[i][j] vo[i]); every sum runs over its terms in index order.  The first NP rows of the block are parked in LDS as float4 chunks
+// [c][T] and streamed through four registers at a time; rows NP.. sit in Mt[0 .. HR-NP).
+template<int NX, int HR, int NP, bool TR>
+GATO_DEV void half_block(const float (*Mt)[NX], const float4* park, int T, const float* w, const float* vo, float* acc, float* tp)
+{
+#pragma unroll
+    for (int i = 0; i < HR; i++) acc[i] = 0.f;
+    if constexpr (TR) {
+#pragma unroll
+        for (int j = 0; j < NX; j++) tp[j] = 0.f;
+    }
+    if constexpr (NP > 0) {
+#pragma unroll
+        for (int c = 0; c < (NP * NX) / 4; c++) {
+            const float4 m4 = park[c * T];
+            const float m[4] = {m4.x, m4.y, m4.z, m4.w};
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int idx = 4 * c + q, i = idx / NX, j = idx % NX;
+                acc[i] = __builtin_fmaf(m[q], w[j], acc[i]);
+                if constexpr (TR) tp[j] = __builtin_fmaf(m[q], vo[i], tp[j]);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = NP; i < HR; i++) {
+#pragma unroll
+        for (int j = 0; j < NX; j++) {
+            const float m = Mt[i - NP][j];
+            acc[i] = __builtin_fmaf(m, w[j], acc[i]);
+            if constexpr (TR) tp[j] = __builtin_fmaf(m, vo[i], tp[j]);
+        }
+    }
+}
+
+template<class M, int MAXT>
+__global__ __launch_bounds__(MAXT) void pcgs_kernel(Buffers bf, int N, int B, uint32_t max_iters, int sqp_iter)
+{
+    constexpr int NQ = M::NQ, NX = 2 * NQ, HR = NX / 2, BR = 3 * NX, BROW = 3 * NX * NX;
+    constexpr int NP = 4;                      // rows of the thread's P^-1 block parked in LDS
+    constexpr int PF4 = (NP * NX) / 4;         // as float4 chunks
+    static_assert(NX % 2 == 0 && (NP * NX) % 4 == 0, "layout");
+    constexpr int PARTS = MAXT <= 256 ? 1 : 2;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    if (bf.ctrl->done) return;
+    const int b = blockIdx.x, t = threadIdx.x, T = blockDim.x;  // T = 4 N, a multiple of 64
+    const int vecp = (N + 2) * NX;
+    float* va = lds;
+    float* vb = va + vecp;
+    float* partA = vb + ((vecp + 3) & ~3);
+    float* partB = partA + 16;
+    float* rowbuf = partB + 16;                // [N nx]: the left-block part of every row's product
+    float* tbuf = rowbuf + N * NX;             // [N + 1][2][nx]: transposed partials of block k, by row half; block N stays zero
+    float4* park = reinterpret_cast<float4*>(tbuf + (N + 1) * 2 * NX) + t;  // [PF4][T]
+    if (t < 32) partA[t] = 0.f;
+    const float abs_tol = 1e-6f;
+    uint32_t iters = 0;
+    const bool skip = bf.converged[b] != 0;    // pcg.cuh:29-32
+
+    if (!skip) {
+        const float eps = bf.pcg_tol[b];
+        const bool mainrole = t >= (T >> 1);
+        const int u = mainrole ? t - (T >> 1) : t;
+        const int k = u >> 1, h = u & 1;
+        const int r0 = k * NX + h * HR;
+        const float* gam = bf.gamma + (size_t)b * vecp;
+        float* lam = bf.lambda + (size_t)b * vecp;
+        float Sm[HR][NX], Pm[HR - NP][NX];
+        {
+            const float* Sg = bf.S + (size_t)b * N * BROW + (size_t)r0 * BR + (mainrole ? NX : 0);
+            const float* Pg = bf.Pinv + (size_t)b * N * BROW + (size_t)r0 * BR + (mainrole ? NX : 0);
+            float prk[NP * NX];
+#pragma unroll
+            for (int i = 0; i < HR; i++) {
+                load_vec<NX, 2>(Sm[i], Sg + i * BR);
+                if (i < NP) load_vec<NX, 2>(prk + i * NX, Pg + i * BR);
+                else load_vec<NX, 2>(Pm[i - NP], Pg + i * BR);
+            }
+#pragma unroll
+            for (int c = 0; c < PF4; c++) park[c * T] = make_float4(prk[4 * c], prk[4 * c + 1], prk[4 * c + 2], prk[4 * c + 3]);
+        }
+        float xv[HR], rv[HR], pv[HR], gv[HR];
+#pragma unroll
+        for (int i = 0; i < HR; i++) {
+            xv[i] = mainrole ? lam[NX + r0 + i] : 0.f;
+            gv[i] = mainrole ? gam[NX + r0 + i] : 0.f;
+        }
+        for (int i = t; i < NX; i += T) {
+            va[i] = 0.f; vb[i] = 0.f;
+            va[vecp - NX + i] = 0.f; vb[vecp - NX + i] = 0.f;
+        }
+        for (int i = t; i < 2 * NX; i += T) tbuf[N * 2 * NX + i] = 0.f;
+        const float* wina = va + (k + (mainrole ? 1 : 0)) * NX;   // the role's window: block k-1 (left) or k (main) of the padded vector
+        const float* winb = vb + (k + (mainrole ? 1 : 0)) * NX;
+        const int own = NX + r0;                                   // the thread's rows in the padded vectors
+
+        // out[i] = row r0 + i of Mx v for the main role; `vec` is the LDS copy of v (published by the caller's barrier); ISP: Mx = P^-1.
+        // The roles are whole wavefronts, so each takes ONE branch per product and runs straight-line code inside it.
+        auto matvec = [&](const float* vec, const float* win, auto isp, float* out) {
+            constexpr bool ISP = decltype(isp)::value;
+            float acc[HR], w[NX];
+            load_vec<NX, 2>(w, win);
+            if (!mainrole) {
+                float tp[NX], vo[HR];
+#pragma unroll
+                for (int i = 0; i < HR; i++) vo[i] = vec[own + i];
+                if constexpr (ISP) half_block<NX, HR, NP, true>(Pm, park, T, w, vo, acc, tp);
+                else half_block<NX, HR, 0, true>(Sm, nullptr, T, w, vo, acc, tp);
+                store_vec<NX, 2>(tbuf + (k * 2 + h) * NX, tp);
+                store_vec<HR, 1>(rowbuf + r0, acc);
+            } else {
+                if constexpr (ISP) half_block<NX, HR, NP, false>(Pm, park, T, w, nullptr, acc, nullptr);
+                else half_block<NX, HR, 0, false>(Sm, nullptr, T, w, nullptr, acc, nullptr);
+            }
+            __syncthreads();
+            if (mainrole) {
+                const float* t0 = tbuf + ((k + 1) * 2 + 0) * NX + h * HR;
+                const float* t1 = tbuf + ((k + 1) * 2 + 1) * NX + h * HR;
+#pragma unroll
+                for (int i = 0; i < HR; i++) out[i] = ((acc[i] + rowbuf[r0 + i]) + t0[i]) + t1[i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < HR; i++) out[i] = 0.f;
+            }
+        };
+        using yes = std::true_type;
+        using no = std::false_type;
+
+        if (mainrole) store_vec<HR, 1>(va + own, xv);
+        __syncthreads();
+        float acc[HR], zv[HR];
+        matvec(va, wina, no{}, acc);  // r = gamma - S x
+#pragma unroll
+        for (int i = 0; i < HR; i++) rv[i] = gv[i] - acc[i];   // both are 0 in the left role
+        if (mainrole) store_vec<HR, 1>(vb + own, rv);
+        __syncthreads();
+        matvec(vb, winb, yes{}, zv);  // z = p = P^-1 r
+        float loc = 0.f;
+#pragma unroll
+        for (int i = 0; i < HR; i++) {
+            pv[i] = zv[i];
+            loc += rv[i] * zv[i];
+        }
+        float rho = block_sum<PARTS>(loc, partA);
+        if (!(fabsf(rho) < abs_tol)) {
+            const float rho_init = fabsf(rho);
+            for (uint32_t it = 0; it < max_iters; it++) {
+                iters++;
+                if (mainrole) store_vec<HR, 1>(va + own, pv);
+                __syncthreads();
+                matvec(va, wina, no{}, acc);  // A p
+                loc = 0.f;
+#pragma unroll
+                for (int i = 0; i < HR; i++) loc += pv[i] * acc[i];
+                const float pAp = block_sum<PARTS>(loc, partB);
+                const float alpha = rho / pAp;
+#pragma unroll
+                for (int i = 0; i < HR; i++) {
+                    xv[i] += alpha * pv[i];
+                    rv[i] -= alpha * acc[i];
+                }
+                if (mainrole) store_vec<HR, 1>(vb + own, rv);
+                __syncthreads();
+                matvec(vb, winb, yes{}, zv);  // z = P^-1 r
+                loc = 0.f;
+#pragma unroll
+                for (int i = 0; i < HR; i++) loc += rv[i] * zv[i];
+                const float rho_new = block_sum<PARTS>(loc, partA);
+                if (fabsf(rho_new) < (abs_tol + eps * rho_init)) break;
+                const float beta = rho_new / rho;
+                rho = rho_new;
+#pragma unroll
+                for (int i = 0; i < HR; i++) pv[i] = zv[i] + beta * pv[i];
+            }
+            if (mainrole) {
+#pragma unroll
+                for (int i = 0; i < HR; i++) lam[NX + r0 + i] = xv[i];
+            }
         }
     }
     if (threadIdx.x == 0) {

@@ -257,6 +257,7 @@ template<class M> static void launch_kkt(GatoSolver* s, hipStream_t st, float dt
 // ---- the PCG launch plan ------------------------------------------------------------------------------------------------
 // Register-resident kernels pcgc_kernel<M, RPT, MAXT, FOLD[, FUSE]>, tried in the order below; choice ids:
 //   4: <2 rows, 3 waves/SIMD>   6: <1 row>   5: <3 rows, 2 waves/SIMD>   2: <3 rows>   3: <2 rows>   1: <6 rows>   0: streaming pcg_kernel
+//   7: pcgs_kernel, symmetric half storage, 4 N threads (long horizons: the system stays on the CU where the others would stream it)
 // Measured at indy7 N=32 B=1024 (profiles/r01d_pcg_variants.txt): 3 rows/thread 151 us, 2 rows 172 us, 1 row 213 us, 6 rows (one wave
 // per trajectory) 217 us per launch.  3 rows per thread first: 256 registers without spills = two wavefronts per SIMD = four 2-wave
 // trajectories per CU, so all 1024 trajectories of C2 are resident at once.
@@ -308,6 +309,25 @@ template<class M> static size_t pcg_fused_lds(const GatoSolver* s)
     return pcg_vec_lds(s) + (fold > park ? fold : park);
 }
 
+// pcgs_kernel: 4 N threads; LDS = the two vectors + partial sums + row partials [N nx] + transposed partials [(N+1) 2 nx] + four parked rows
+// of every thread's P^-1 block (float4 [nx][T])
+static size_t pcgs_lds(const GatoSolver* s)
+{
+    const size_t T = 4 * (size_t)s->N, nx = s->nx;
+    return ((size_t)2 * s->vecp + 36 + (size_t)s->N * nx + (size_t)(s->N + 1) * 2 * nx) * sizeof(float) + (4 * nx / 4) * T * 16;
+}
+template<class M> static bool pcgs_grant(const GatoSolver* s)
+{
+    if (4 * s->N <= 256) return grant_lds(reinterpret_cast<const void*>(&pcgs_kernel<M, 256>), pcgs_lds(s));
+    return grant_lds(reinterpret_cast<const void*>(&pcgs_kernel<M, 512>), pcgs_lds(s));
+}
+template<class M> static void launch_pcgs(GatoSolver* s, hipStream_t st, int sqp_iter)
+{
+    const int T = 4 * s->N;
+    if (T <= 256) hipLaunchKernelGGL((pcgs_kernel<M, 256>), dim3(s->B), dim3(T), pcgs_lds(s), st, s->bf, s->N, s->B, s->p.max_pcg_iters, sqp_iter);
+    else hipLaunchKernelGGL((pcgs_kernel<M, 512>), dim3(s->B), dim3(T), pcgs_lds(s), st, s->bf, s->N, s->B, s->p.max_pcg_iters, sqp_iter);
+}
+
 template<class M> static int plan_pcg(GatoSolver* s)
 {
     constexpr int NX = 2 * M::NQ;
@@ -322,10 +342,12 @@ template<class M> static int plan_pcg(GatoSolver* s)
     else if ((v == 100 || v == 2) && pcgc_fits<M, 3>(s)) choice = 2;
     else if ((v == 100 || v == 3) && pcgc_fits<M, 2>(s)) choice = 3;
     else if ((v == 100 || v == 1) && pcgc_fits<M, 6>(s)) choice = 1;
+    // symmetric half storage: asked for (7), or the default where no full-storage kernel holds the system (iiwa14 N = 128)
+    if ((v == 7 || (v == 100 && choice == 0)) && s->N >= 16 && 4 * s->N <= 512 && pcgs_grant<M>(s)) choice = 7;
     s->pcg_choice = choice;
     // the kernel that will run forms the stair off-diagonals itself when the two fold buffers + the vectors fit one CU's LDS and the
     // runtime grants them; otherwise schur2_kernel is launched (launch_schur) and the kernel reads the complete P^-1
-    bool fold = fold_wanted && choice != 0 && pcg_vec_lds(s) + pcg_fold_lds(s) <= 150 * 1024;
+    bool fold = fold_wanted && choice != 0 && choice != 7 && pcg_vec_lds(s) + pcg_fold_lds(s) <= 150 * 1024;
     if (fold) {
         switch (choice) {
             case 4: fold = pcgc_grant_fold<M, 2, 3>(s); break;
@@ -398,6 +420,7 @@ template<class M> static void launch_pcg(GatoSolver* s, hipStream_t st, int sqp_
         case 2: launch_pcgc<M, 3>(s, st, sqp_iter, write_p); return;
         case 3: launch_pcgc<M, 2>(s, st, sqp_iter, write_p); return;
         case 1: launch_pcgc<M, 6>(s, st, sqp_iter, write_p); return;
+        case 7: launch_pcgs<M>(s, st, sqp_iter); return;
         default: break;
     }
     const int T1 = ((rows + 63) / 64) * 64;

@@ -628,3 +628,30 @@ def test_rho_reset_rule_without_adaptation():
     np.testing.assert_array_equal(nat.read("rho"), orc.buf("rho"))
     failed = np.any(ro["ls_step_size"] < 0, axis=0)
     assert np.all(orc.buf("rho")[failed & (rho > 10)] == np.float32(1e-3)) and np.all(orc.buf("rho")[~failed] == rho[~failed])
+
+
+@pytest.mark.parametrize("plant,N,B", [("indy7", 32, 6), ("iiwa14", 64, 3), ("iiwa14", 16, 5), ("indy7", 128, 2)])
+def test_symmetric_half_storage_pcg_kernel(plant, N, B, monkeypatch):
+    """pcgs_kernel (S and P^-1 in symmetric half storage, right blocks as transposed accumulates of the next block row's left block --
+    the default only where nothing else keeps the system on the CU, iiwa14 N = 128) forced on configurations the full-storage kernels
+    serve: same system, same PCG, so lambda and the iteration counts agree with the oracle like theirs, and whole solves stay together."""
+    from gato_amd._lib import NativeSolver
+    from oracle.oracle import OracleSolver
+    p = dict(DEFAULT_SOLVER_PARAMS, max_sqp_iters=1)
+    pr = fig8_problem(plant, N, B, f_ext_std=1.0)
+    monkeypatch.setenv("GATO_PCG_VARIANT", "7")
+    sym = NativeSolver(plant, N, B, dt=DT, **p)
+    monkeypatch.delenv("GATO_PCG_VARIANT")
+    orc = OracleSolver(plant, N, B, dt=DT, **p)
+    for s in (sym, orc):
+        s.set_f_ext_batch(pr["f_ext"])
+    xu, xs, ref = pr["xu"], pr["x_s"], pr["ref"]
+    for st in ("kkt", "schur", "pcg"):
+        sym.stage(st, xu, DT, xs, ref)
+    orc.setup_kkt(xu, xs, ref, DT); orc.form_schur(); orc.pcg()
+    assert np.abs(sym.read("pcg_iters").astype(int) - orc.ibuf("pcg_iters", (B,))).max() <= 1
+    assert rel(sym.read("lambda").reshape(B, N + 2, sym.nx), orc.buf("lambda")) < 1e-3
+    rs = sym.solve(xu, DT, xs, ref)
+    ro = orc.solve(xu, DT, xs, ref)
+    np.testing.assert_array_equal(rs["ls_step_size"], ro["ls_step_size"])
+    assert traj_err(rs["XU"], ro["XU"]).max() < 2e-3
