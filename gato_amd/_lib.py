@@ -18,7 +18,7 @@ SYMBOLS = [
     "gato_ee_pos", "gato_debug_read", "gato_debug_write", "gato_debug_stage", "gato_set_profiling", "gato_get_stage_times_us",
     "gato_last_error", "gato_version", "gato_reset_async", "gato_copy_final_merit_device", "gato_set_cost_weights_batch",
     "gato_synchronize", "gato_sim_forward_device", "gato_select_best", "gato_select_best_device",
-    "gato_plant_rk4", "gato_fk_placements",
+    "gato_plant_rk4", "gato_fk_placements", "gato_set_linear_solver",
 ]
 
 
@@ -76,6 +76,7 @@ def load():
     for n in ("gato_reset_dual", "gato_reset_rho"):
         getattr(L, n).argtypes = [vp]
     L.gato_set_rho_adaptation.argtypes = [vp, C.c_int]
+    L.gato_set_linear_solver.argtypes = [vp, C.c_int]
     L.gato_sim_forward.argtypes = [vp, fp, fp, fp, C.c_float]
     L.gato_ee_pos.argtypes = [vp, fp, C.c_int, fp]
     L.gato_debug_read.argtypes = [vp, C.c_char_p, fp, C.c_uint64, C.POINTER(C.c_uint64)]
@@ -122,7 +123,7 @@ def fk_placements(plant, q):
 
 
 PARAM_ORDER = [f[0] for f in GatoParams._fields_]
-STAGES = {"merit8": 0, "kkt": 1, "schur": 2, "pcg": 3, "dz": 4, "line_search": 5, "merit1": 6}
+STAGES = {"merit8": 0, "kkt": 1, "schur": 2, "pcg": 3, "dz": 4, "line_search": 5, "merit1": 6, "direct": 7}
 
 
 class NativeSolver:
@@ -240,6 +241,10 @@ class NativeSolver:
 
     def set_rho_adaptation(self, enabled):
         _chk(load().gato_set_rho_adaptation(self.h, int(bool(enabled))))
+
+    def set_linear_solver(self, mode):
+        """"pcg" (the reference's solver) or "direct" (block-tridiagonal LU sweep; extension)"""
+        _chk(load().gato_set_linear_solver(self.h, {"pcg": 0, "direct": 1}[mode]))
 
     def sim_forward(self, xk, uk, dt):
         out = np.zeros((self.B, self.nx), np.float32)

@@ -1952,6 +1952,149 @@ __global__ __launch_bounds__(MAXT) void pcgs_kernel(Buffers bf, int N, int B, ui
 }
 
 // =========================================================================================================================
+// DIRECT solve of the block-tridiagonal Schur system S lambda = gamma (opt-in: gato_set_linear_solver; the north-star's "block-
+// tridiagonal Riccati/Schur solve").  The reference only has PCG; this mode replaces pcg.cuh:14-148 by a block
+// LU sweep without pivoting (S is symmetric negative definite: -S is the Schur complement of the regularised KKT system):
+//     D_0 = main_0,  g_0 = gamma_0;      W_k = left_k D_{k-1}^-1,  D_k = main_k - W_k left_k^T,  g_k = gamma_k - W_k g_{k-1}   (k = 1 .. N-1)
+//     lambda_{N-1} = D_{N-1}^-1 g_{N-1};  lambda_k = D_k^-1 (g_k - left_{k+1}^T lambda_{k+1})                                     (k = N-2 .. 0)
+// (right_k = left_{k+1}^T exactly, see pcgs_kernel).  The recursion is serial in k -- this is the Riccati depth -- so a trajectory gets a
+// group of 16 lanes (lane r < nx owns row r of the running blocks; 4 trajectories per wavefront): D^-1 by Gauss-Jordan in the
+// arithmetic of block::invertMatrix's one-matrix form (linalg.cuh:364-519), pivot rows by ds_bpermute, operand blocks through LDS (the
+// workgroup is ONE wavefront, so its barriers cost no wait: they only order the lanes' LDS writes before the group's reads).  D_k^-1 is kept for the back substitution in the P^-1 buffer's
+// main blocks (the preconditioner is not formed in this mode).  Cost: N serial steps of ~2 nx^3 flops each, no iteration count --
+// the solve time no longer depends on the conditioning (rho), and lambda is exact to fp32 rounding instead of PCG's exit tolerance.
+// =========================================================================================================================
+template<class M>
+__global__ __launch_bounds__(64) void btd_direct_kernel(Buffers bf, int N, int B, int sqp_iter)
+{
+    constexpr int NQ = M::NQ, NX = 2 * NQ, BR = 3 * NX, BROW = 3 * NX * NX, LD = NX + 2;  // LD: LDS row stride (8-byte aligned rows, fewer conflicts)
+    __shared__ __attribute__((aligned(16))) float smem[4][3][NX * LD];
+    if (bf.ctrl->done) return;
+    const int grp = threadIdx.x >> 4, r = threadIdx.x & 15;
+    const int b = blockIdx.x * 4 + grp;
+    const bool live = b < B;
+    const int bb = live ? b : B - 1;            // spare groups shadow the last trajectory and store nothing
+    const bool act = r < NX;
+    const int rr = act ? r : 0;
+    float* sA = smem[grp][0];                   // operand block (D^-1 of the previous block row, all rows)
+    float* sL = smem[grp][1];                   // left_k, all rows
+    float* sP = smem[grp][2];                   // pivot rows / vectors
+    const float* S = bf.S + (size_t)bb * N * BROW;
+    float* Dinv = bf.Pinv + (size_t)bb * N * BROW;
+    const float* gam = bf.gamma + (size_t)bb * (N + 2) * NX;
+    float* lam = bf.lambda + (size_t)bb * (N + 2) * NX;
+    const bool skip = bf.converged[bb] != 0;
+
+    if (!skip) {
+        float Di[NX];        // row rr of D_{k-1}^-1
+        float g_prev = 0.f;  // entry rr of g_{k-1}
+        for (int k = 0; k < N; k++) {
+            const float* Sk = S + (size_t)k * BROW + (size_t)rr * BR;
+            float D[NX], Lr[NX], g;
+            gload_vec<NX>(D, Sk + NX);            // main_k, row rr
+            g = gam[(k + 1) * NX + rr];
+            if (k > 0) {
+                gload_vec<NX>(Lr, Sk);            // left_k, row rr
+                // publish D_{k-1}^-1 (rows), left_k (rows) and g_{k-1}
+#pragma unroll
+                for (int c = 0; c < NX; c++) {
+                    sA[rr * LD + c] = Di[c];
+                    sL[rr * LD + c] = Lr[c];
+                }
+                sP[rr] = g_prev;
+                __syncthreads();  // one wavefront per workgroup: orders the lanes' LDS writes before the group's reads (no hardware wait)
+                // W row rr = left_k[rr][:] D_{k-1}^-1
+                float W[NX];
+#pragma unroll
+                for (int c = 0; c < NX; c++) W[c] = 0.f;
+#pragma unroll
+                for (int j = 0; j < NX; j++) {
+#pragma unroll
+                    for (int c = 0; c < NX; c++) W[c] = __builtin_fmaf(Lr[j], sA[j * LD + c], W[c]);
+                }
+                // D_k row rr = main_k[rr][:] - W[rr][:] left_k^T ;  g_k[rr] = gamma_k[rr] - W[rr][:] g_{k-1}
+                float wg = 0.f;
+#pragma unroll
+                for (int j = 0; j < NX; j++) wg = __builtin_fmaf(W[j], sP[j], wg);
+                g = g - wg;
+#pragma unroll
+                for (int c = 0; c < NX; c++) {
+                    float acc = 0.f;
+#pragma unroll
+                    for (int j = 0; j < NX; j++) acc = __builtin_fmaf(W[j], sL[c * LD + j], acc);
+                    D[c] = D[c] - acc;
+                }
+            }
+            // D_k^-1 by Gauss-Jordan without pivoting, rows distributed over the lanes (in place: column p becomes column p of the inverse)
+#pragma unroll
+            for (int p = 0; p < NX; p++) {
+                float prow[NX];
+#pragma unroll
+                for (int c = 0; c < NX; c++) prow[c] = __shfl(D[c], p, 16);   // the pivot row from its owner lane (ds_bpermute, like schur1_kernel)
+                const float pvInv = 1.0f / prow[p];
+                const float f = D[p] * pvInv;
+                const bool owner = (rr == p);
+#pragma unroll
+                for (int c = 0; c < NX; c++) {
+                    float x, yv;
+                    if (c == p) {
+                        yv = 0.f - f;
+                        x = 1.0f;
+                    } else {
+                        x = D[c];
+                        yv = x - f * prow[c];
+                    }
+                    const float piv = x * pvInv;
+                    D[c] = owner ? piv : yv;
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < NX; c++) Di[c] = D[c];
+            g_prev = g;
+            __syncthreads();  // the group is done reading sA / sL / sP before the next block row overwrites them
+            if (live && act) {
+                gstore_vec<NX>(Dinv + (size_t)k * BROW + (size_t)rr * BR + NX, Di);
+                lam[(k + 1) * NX + rr] = g;      // g_k parks in lambda until the back substitution overwrites it
+            }
+        }
+        // back substitution; Di / g_prev hold block N-1
+        float lnext = 0.f;
+        for (int k = N - 1; k >= 0; k--) {
+            float rhs = g_prev;
+            if (k < N - 1) {
+                // rhs = g_k - left_{k+1}^T lambda_{k+1}: entry rr = sum_i left_{k+1}[i][rr] lambda_{k+1}[i]
+                const float* Ln = S + (size_t)(k + 1) * BROW;
+                sP[rr] = lnext;
+                __syncthreads();
+                float acc = 0.f;
+#pragma unroll
+                for (int i = 0; i < NX; i++) acc = __builtin_fmaf(Ln[(size_t)i * BR + rr], sP[i], acc);
+                rhs = rhs - acc;
+            }
+            sP[2 * NX + rr] = rhs;
+            __syncthreads();
+            float l = 0.f;
+#pragma unroll
+            for (int c = 0; c < NX; c++) l = __builtin_fmaf(Di[c], sP[2 * NX + c], l);
+            lnext = l;
+            __syncthreads();
+            if (k > 0) {  // fetch block k-1 before lambda_k overwrites nothing it needs (g_{k-1} sits in lambda's slot k-1)
+                gload_vec<NX>(Di, Dinv + (size_t)(k - 1) * BROW + (size_t)rr * BR + NX);
+                g_prev = lam[k * NX + rr];
+            }
+            if (live && act) lam[(k + 1) * NX + rr] = l;
+        }
+    }
+    if (live && r == 0) {
+        // statistics: one "iteration"; a trajectory is never declared converged by the PCG rule (0 iterations, bsqp.cuh:153) in this mode
+        const uint32_t it = skip ? 0u : 1u;
+        bf.pcg_iters[b] = it;
+        bf.st_pcg_iters[(size_t)sqp_iter * B + b] = (int32_t)it;
+        if (skip) atomicAdd(&bf.num_solved[sqp_iter], 1u);
+    }
+}
+
+// =========================================================================================================================
 // dz recovery (computeDzBatchedKernel, schur_linsys.cuh:316-431), one lane per (b,k); q, r are overwritten by the KKT residuals
 // =========================================================================================================================
 // dz of knot k of trajectory b (computeDz, kkt.cuh), also left in `mirror` (the trajectory's step in LDS) when given

@@ -120,6 +120,12 @@ class PyBSQP {
     void reset_dual() { chk(gato_reset_dual(s_)); }
     void reset_rho() { chk(gato_reset_rho(s_)); }
     void set_rho_adaptation(bool enabled) { chk(gato_set_rho_adaptation(s_, enabled)); }
+    // extension: "pcg" (reference) | "direct" (block-tridiagonal LU sweep on S), SURVEY.md 8(f)4
+    void set_linear_solver(const std::string& mode)
+    {
+        if (mode != "pcg" && mode != "direct") throw py::value_error("linear solver: 'pcg' or 'direct'");
+        chk(gato_set_linear_solver(s_, mode == "direct" ? GATO_LINSOLVE_DIRECT : GATO_LINSOLVE_PCG));
+    }
 
     // PyBSQP::sim_forward, bindings.cu:180-194
     py::array_t<float> sim_forward(farray xk, farray uk, float dt)
@@ -234,6 +240,7 @@ PYBIND11_MODULE(_gato_ext, m)
         .def("sim_forward", &PyBSQP::sim_forward)
         .def("reset_rho", &PyBSQP::reset_rho)
         .def("set_rho_adaptation", &PyBSQP::set_rho_adaptation)
+        .def("set_linear_solver", &PyBSQP::set_linear_solver)
         .def("ee_pos", &PyBSQP::ee_pos)
         .def("select_best", &PyBSQP::select_best)
         .def("plant_rk4", &PyBSQP::plant_rk4)

@@ -64,6 +64,7 @@ struct GatoSolver {
     // streaming pcg_kernel), whether it forms the stair off-diagonals itself (then schur2_kernel is not launched) and whether the
     // Schur complement is formed inside it.  Tuning overrides GATO_PCG_VARIANT / GATO_PCG_FOLD are read there, never in the solve loop.
     int pcg_choice, pcg_fold, pcg_fused;
+    int linear_solver;  // 0: PCG (the reference's solver, pcg.cuh), 1: direct block-tridiagonal sweep (gato_set_linear_solver)
     float *d_sim_x, *d_sim_u, *d_sim_out;  // staging of sim_forward ([nx], [nu], [B][nx]), allocated with the solver
     float *d_sel_xm, *d_sel_err;           // gato_select_best: measured state [nx], per-hypothesis error [B]
     int32_t* d_sel_best;                   // [0] arg-min, [1] completion counter of the selection kernel
@@ -126,6 +127,7 @@ static int create_impl(GatoSolver* s, int plant, int N, int B, const GatoParams*
     s->p = *params;
     s->cw = Costs{params->q_cost, params->qd_cost, params->u_cost, params->N_cost, params->q_lim_cost, params->vel_lim_cost, params->ctrl_lim_cost};
     s->adapt_rho = 1;
+    s->linear_solver = 0;
     s->fuse_schur = getenv("GATO_SCHUR_FUSED") ? atoi(getenv("GATO_SCHUR_FUSED")) : 1;
     s->fuse_step = getenv("GATO_STEP_FUSED") ? atoi(getenv("GATO_STEP_FUSED")) : 1;
     s->schur_rowlane = getenv("GATO_SCHUR_ROWLANE") ? atoi(getenv("GATO_SCHUR_ROWLANE")) : (s->nq % 2);
@@ -371,7 +373,7 @@ template<class M> static int plan_pcg(GatoSolver* s)
 }
 static int plan_pcg_dispatch(GatoSolver* s) { return s->plant == GATO_PLANT_INDY7 ? plan_pcg<Indy7>(s) : plan_pcg<Iiwa14>(s); }
 
-template<class M> static void launch_schur(GatoSolver* s, hipStream_t st, float dt, bool force_stair = false)
+template<class M> static void launch_schur(GatoSolver* s, hipStream_t st, float dt, bool force_stair = false, bool no_stair = false)
 {
     // lanes per (b,k): 4 with rows 3l..3l+2 (indy7); nq odd (iiwa14) divides evenly only into 2 x 7 rows -- heavier on registers
     // (AGPR moves, a few spills) but still ahead of a lane-per-knot kernel pair: 185 vs 238 us per launch at C3
@@ -381,7 +383,7 @@ template<class M> static void launch_schur(GatoSolver* s, hipStream_t st, float 
         hipLaunchKernelGGL((schur1_kernel<M>), dim3(cdiv(probs * 16, 256), 2), dim3(256), 0, st, s->bf, s->N, s->B, dt);
     else
         hipLaunchKernelGGL((schurq_kernel<M, LPP>), dim3(cdiv(probs * LPP, 256), 2), dim3(256), 0, st, s->bf, s->N, s->B, dt);
-    if (force_stair || !s->pcg_fold) hipLaunchKernelGGL((schur2_kernel<M>), dim3(cdiv(probs, 64)), dim3(64), 0, st, s->bf, s->N, s->B);
+    if (!no_stair && (force_stair || !s->pcg_fold)) hipLaunchKernelGGL((schur2_kernel<M>), dim3(cdiv(probs, 64)), dim3(64), 0, st, s->bf, s->N, s->B);
 }
 
 template<class M, int RPT, int FORCE_WPS = 0> static void launch_pcgc(GatoSolver* s, hipStream_t st, int sqp_iter, int write_p)
@@ -440,6 +442,11 @@ template<class M> static void launch_pcg(GatoSolver* s, hipStream_t st, int sqp_
         }
     }
 }
+// opt-in direct solve of S lambda = gamma: 16 lanes per trajectory, 4 trajectories per 64-thread workgroup
+template<class M> static void launch_direct(GatoSolver* s, hipStream_t st, int sqp_iter)
+{
+    hipLaunchKernelGGL((btd_direct_kernel<M>), dim3(cdiv(s->B, 4)), dim3(64), 0, st, s->bf, s->N, s->B, sqp_iter);
+}
 template<class M> static void launch_dz(GatoSolver* s, hipStream_t st, float dt, int sqp_iter)
 {
     hipLaunchKernelGGL((dz_kernel<M>), dim3(cdiv((long)s->B * s->N, 256)), dim3(256), 0, st, s->bf, s->N, s->B, dt, sqp_iter);
@@ -493,10 +500,15 @@ template<class M> static int solve_impl(GatoSolver* s, float* d_xu, float dt, co
     mark(s, st, ST_MERIT, ei);
     const uint32_t iters = s->p.max_sqp_iters <= s->max_iters_alloc ? s->p.max_sqp_iters : s->max_iters_alloc;
     for (uint32_t it = 0; it < iters; it++) {
-        const bool fused = s->pcg_fused != 0;
+        const bool direct = s->linear_solver == 1;
+        const bool fused = s->pcg_fused != 0 && !direct;
         launch_kkt<M>(s, st, dt, (int)it, fused ? 1 : 0);
         mark(s, st, ST_KKT, ei);
-        if (fused) {
+        if (direct) {
+            launch_schur<M>(s, st, dt, false, true);   // S and gamma only: no preconditioner in this mode
+            mark(s, st, ST_SCHUR, ei);
+            launch_direct<M>(s, st, (int)it);
+        } else if (fused) {
             launch_pcg_fused<M>(s, st, dt, (int)it);
         } else {
             launch_schur<M>(s, st, dt);
@@ -715,6 +727,13 @@ extern "C" int gato_copy_final_merit_device(GatoSolver* s, float* d_out, void* s
     if (!s || !d_out) return fail(GATO_ERR_INVALID, "null argument");
     GUARD(s);
     HIPCHK(hipMemcpyAsync(d_out, s->bf.merit_cur, s->B * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return GATO_OK;
+}
+extern "C" int gato_set_linear_solver(GatoSolver* s, int mode)
+{
+    if (!s) return fail(GATO_ERR_INVALID, "null solver");
+    if (mode != GATO_LINSOLVE_PCG && mode != GATO_LINSOLVE_DIRECT) return fail(GATO_ERR_INVALID, "unknown linear solver (0 = PCG, 1 = direct)");
+    s->linear_solver = mode;
     return GATO_OK;
 }
 extern "C" int gato_set_rho_adaptation(GatoSolver* s, int enabled)
@@ -950,6 +969,7 @@ template<class M> static int stage_impl(GatoSolver* s, int stage, float dt, floa
         case 1: launch_kkt<M>(s, st, dt, 0); break;
         case 2: launch_schur<M>(s, st, dt, true); break;   // stage tests read the complete P^-1
         case 3: launch_pcg<M>(s, st, 0, 1); break;
+        case 7: launch_direct<M>(s, st, 0); break;
         case 4: launch_dz<M>(s, st, dt, 0); break;
         case 5: launch_ls(s, st, 0, 0); break;
         case 6: launch_merit<M>(s, st, 1, dt, 0, -1, bf.merit_cur); break;

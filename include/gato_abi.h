@@ -102,6 +102,13 @@ int gato_set_cost_weights_batch(GatoSolver* s, const float* w);
 int gato_reset_dual(GatoSolver* s);
 int gato_reset_rho(GatoSolver* s);
 int gato_set_rho_adaptation(GatoSolver* s, int enabled);
+/* EXTENSION (the north-star's "block-tridiagonal Riccati/Schur solve"): how S lambda = gamma is solved in every SQP
+ * iteration.  GATO_LINSOLVE_PCG (default) is the reference's warm-started, stair-preconditioned PCG (gato/bsqp/kernels/pcg.cuh);
+ * GATO_LINSOLVE_DIRECT is a block LU sweep over the block-tridiagonal system (no preconditioner, no iteration count, lambda exact to
+ * fp32 rounding; pcg_iters reports 1 and no trajectory is ever flagged converged by the "0 PCG iterations" rule). */
+#define GATO_LINSOLVE_PCG 0
+#define GATO_LINSOLVE_DIRECT 1
+int gato_set_linear_solver(GatoSolver* s, int mode);
 
 /* BSQP::sim_forward / PyBSQP::sim_forward (bsqp.cuh:91, bindings.cu:180-194): one integrator step of the SHARED (xk, uk) under the
  * B stored wrench hypotheses; xkp1 is [B][nx] on the host. */
@@ -137,7 +144,7 @@ int gato_ee_pos(GatoSolver* s, const float* q, int n, float* out);
 int gato_debug_read(GatoSolver* s, const char* name, float* out, uint64_t count, uint64_t* len);
 int gato_debug_write(GatoSolver* s, const char* name, const float* in, uint64_t count);
 /* Runs ONE stage of an SQP iteration on device buffers previously filled (tests drive the stages one at a time):
- * stage: 0 merit(8 alphas) 1 kkt 2 schur(+stair) 3 pcg 4 dz 5 line-search 6 merit(1, dz ignored) */
+ * stage: 0 merit(8 alphas) 1 kkt 2 schur(+stair) 3 pcg 4 dz 5 line-search 6 merit(1, dz ignored) 7 direct solve (instead of 3) */
 int gato_debug_stage(GatoSolver* s, int stage, float* xu, float timestep, const float* x_s, const float* ref, float* out);
 
 /* Per-stage device time of the last gato_solve / gato_solve_device call when profiling was enabled (hipEvents around each

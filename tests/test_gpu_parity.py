@@ -655,3 +655,60 @@ def test_symmetric_half_storage_pcg_kernel(plant, N, B, monkeypatch):
     ro = orc.solve(xu, DT, xs, ref)
     np.testing.assert_array_equal(rs["ls_step_size"], ro["ls_step_size"])
     assert traj_err(rs["XU"], ro["XU"]).max() < 2e-3
+
+
+@pytest.mark.parametrize("plant,N,B", [("indy7", 32, 9), ("iiwa14", 64, 5), ("iiwa14", 128, 2), ("indy7", 8, 3)])
+def test_direct_block_tridiagonal_solver(plant, N, B):
+    """Opt-in mode (gato_set_linear_solver): a block LU sweep over S lambda = gamma instead of PCG.  From the same S and
+    gamma its lambda must (a) solve the system -- checked against a float64 dense solve of the DEVICE's own S, 2e-4 of |lambda| -- and
+    (b) agree with a PCG run at its floor to 1e-3 (PCG's own fp32 floor); whole solves in this mode descend like the PCG ones."""
+    from gato_amd._lib import NativeSolver
+    p = dict(DEFAULT_SOLVER_PARAMS, max_sqp_iters=1)
+    pr = fig8_problem(plant, N, B, f_ext_std=1.0)
+    xu, xs, ref = pr["xu"], pr["x_s"], pr["ref"]
+    d = NativeSolver(plant, N, B, dt=DT, **p)
+    d.set_f_ext_batch(pr["f_ext"])
+    nx = d.nx
+    for st in ("kkt", "schur", "direct"):
+        d.stage(st, xu, DT, xs, ref)
+    lam = d.read("lambda").reshape(B, N + 2, nx).astype(np.float64)
+    S = d.read("S").reshape(B, N, nx, 3 * nx).astype(np.float64)
+    gam = d.read("gamma").reshape(B, N + 2, nx).astype(np.float64)
+    assert np.all(d.read("pcg_iters") == 1)
+    for b in range(B):
+        Sd = np.zeros((N * nx, N * nx))
+        for k in range(N):
+            for j, kk in enumerate((k - 1, k, k + 1)):
+                if 0 <= kk < N:
+                    Sd[k * nx:(k + 1) * nx, kk * nx:(kk + 1) * nx] = S[b, k][:, j * nx:(j + 1) * nx]
+        exact = np.linalg.solve(Sd, gam[b, 1:N + 1].reshape(-1))
+        err = np.abs(lam[b, 1:N + 1].reshape(-1) - exact).max() / np.abs(exact).max()
+        _report("direct_vs_dense_f64", plant=plant, N=N, b=b, err=err, cond=float(np.linalg.cond(Sd)))
+        assert err < 2e-4, (b, err)                                   # fp32 sweep on a system of condition 1e9 .. 1e10 (measured <= 9e-5)
+        assert np.all(lam[b, 0] == 0) and np.all(lam[b, N + 1] == 0)  # the padding blocks stay zero
+    # (b) against PCG at its floor, same device blocks
+    q = NativeSolver(plant, N, B, dt=DT, **dict(p, **TIGHT))
+    q.set_f_ext_batch(pr["f_ext"])
+    for st in ("kkt", "schur", "pcg"):
+        q.stage(st, xu, DT, xs, ref)
+    lp = q.read("lambda").reshape(B, N + 2, nx).astype(np.float64)
+    e = np.abs(lam - lp).reshape(B, -1).max(axis=1) / np.abs(lp).reshape(B, -1).max(axis=1)
+    _report("direct_vs_pcg_floor", plant=plant, N=N, err=e.max())
+    assert e.max() < 1e-3, e   # measured 3e-5 .. 4e-4: PCG at its fp32 floor is the less accurate of the two (the sweep is within 9e-5 of float64)
+    # whole solves in direct mode
+    p4 = dict(DEFAULT_SOLVER_PARAMS, max_sqp_iters=4)
+    sd, sp = NativeSolver(plant, N, B, dt=DT, **p4), NativeSolver(plant, N, B, dt=DT, **dict(p4, **TIGHT))
+    for s in (sd, sp):
+        s.set_f_ext_batch(pr["f_ext"])
+    sd.set_linear_solver("direct")
+    rd, rp = sd.solve(xu, DT, xs, ref), sp.solve(xu, DT, xs, ref)
+    assert rd["iters_done"] == 4 and np.all(rd["pcg_iters"] == 1) and np.all(rd["kkt_converged"] == 0)
+    assert np.all(rd["final_merit"] < rd["initial_merit"])
+    np.testing.assert_array_equal(rd["ls_step_size"][0], rp["ls_step_size"][0])     # same first step as PCG at its floor
+    assert np.median(rd["final_merit"] / rp["final_merit"]) < 1.2                    # and a comparable descent over 4 iterations
+    sd.set_linear_solver("pcg")                                                      # and back: the PCG path is untouched
+    sd.reset_dual(); sd.reset_rho()
+    r0 = sd.solve(xu, DT, xs, ref)
+    sp0 = NativeSolver(plant, N, B, dt=DT, **p4)
+    sp0.set_f_ext_batch(pr["f_ext"])
+    np.testing.assert_array_equal(r0["XU"], sp0.solve(xu, DT, xs, ref)["XU"])
