@@ -51,6 +51,38 @@ def stage_bytes(nq, N, fused_schur, fused_step):
     return out
 
 
+def pcg_flops(nq, N, pcg_iters_all, fused_schur):
+    """Algorithmic flops of ONE launch of the PCG kernel family over the whole batch (mul + add = 2), counted from the iteration
+    counts the device reports -- not an estimate of the reference's dense algebra (SURVEY.md 8(d)'s F_schur etc. are for that):
+      per PCG iteration and trajectory: two block-tridiagonal products 2 x 2 (3 nx)(N nx), three axpys 3 x 2 N nx, two dots 2 x 2 N nx
+      (pcg.cuh:96-141); before the loop: r = gamma - S x, z = P^-1 r, one dot.
+      fused kernel only, per knot: phi = A Q^-1 (q block dense nq^2, qd block diagonal), theta = Q^-1 + phi A^T + (B R^-1) B^T,
+      gamma (4 products), the Gauss-Jordan inverse of theta (2 nx^3) and the stair fold (2 products of nx^3)  (schur_linsys.cuh:14-260).
+    Returns flops per launch averaged over the launches of the solve."""
+    nx, nu = 2 * nq, nq
+    rows = N * nx
+    mv = 2 * 3 * nx * rows
+    per_iter = 2 * mv + 3 * 2 * rows + 2 * 2 * rows
+    pre = 2 * mv + 2 * rows
+    schur = 0
+    if fused_schur:
+        phi = 2 * nx * nq * nq + nx * nq
+        theta = 2 * nx * nx * nx + 2 * nx * nu * nx + nx * nu
+        gam = 2 * nx * (nq + 1 + nx + nu)
+        schur = N * (phi + theta + gam + 2 * nx ** 3 + 2 * 2 * nx ** 3)
+    it = np.asarray(pcg_iters_all, np.float64)            # [launches][B]
+    return float((it.sum(axis=1) * per_iter + it.shape[1] * (pre + schur)).mean())
+
+
+def source_hash():
+    """hash of the kernel sources this run executes; profiles/pmc_summary.json carries the one its counters were measured on"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("gato_amd/csrc/kernels.hpp", "gato_amd/csrc/rbd.hpp", "gato_amd/csrc/solver.hip", "gato_amd/csrc/robot_models.hpp"):
+        h.update(open(os.path.join(ROOT, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def usable_cores():
     """Host threads this process may actually use: affinity mask, capped by the cgroup CPU quota when there is one."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -207,13 +239,32 @@ def main():
         dom_bytes = sb[dom] * B
     achieved = dom_bytes / (per_launch_us[dom] * 1e-6) / 1e9
     iter_bytes = sum(sb[k] for k in ("kkt", "schur", "pcg", "dz", "merit", "line_search"))  # per trajectory and SQP iteration
-    traffic = None
+    # both roofs of the dominant kernel (the PCG launch): HBM from the algorithmic bytes, fp32 VALU from the flops the device's own
+    # iteration counts imply; `bound` is the larger fraction.  The launch is latency-shaped: both are small.
+    hbm_frac = achieved / HBM_PEAK_GBS
+    valu = None
+    if dom == "pcg":
+        fl = pcg_flops(NativeSolver_nq(plant), N, st["pcg_iters_all"], fused_schur)
+        tf = fl / (per_launch_us[dom] * 1e-6) / 1e12
+        valu = {"achieved": tf, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP32_PEAK_TFLOPS, "algorithmic_flops_per_launch": fl}
+    # counter-measured traffic and issue-side counters of the profiled build (tools/profile_round.sh + tools/summarize_pmc.py)
+    traffic, pmc = None, {}
     pmc_path = os.path.join(ROOT, "profiles", "pmc_summary.json")
     if os.path.exists(pmc_path):
         try:
-            traffic = json.load(open(pmc_path)).get(dom, {}).get("hbm_bytes_per_launch")
+            js = json.load(open(pmc_path))
+            pat = {"pcg": "pcg", "kkt": "kkt_kernel", "merit": "step_kernel"}.get(dom, dom)
+            rows = [(k, v) for k, v in js.get("c2", {}).items() if pat in k]
+            if rows:
+                k, v = max(rows, key=lambda kv: kv[1].get("pct_of_gpu_time", 0.0))
+                traffic = v.get("hbm_bytes")
+                pmc = {"kernel": k, "profiled_build": js.get("build"), "this_build": source_hash(), "build_matches": js.get("build") == source_hash(),
+                       "rocprof_avg_us": v.get("avg_us"), "valu_issue_frac": v.get("valu_issue_frac"), "lds_bank_conflict_frac": v.get("lds_bank_conflict_frac"),
+                       "mfma_busy_cycles": v.get("mfma_busy_cycles")}
         except Exception:
-            traffic = None
+            traffic, pmc = None, {}
+    hbm = {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_frac, "algorithmic_bytes_per_launch": dom_bytes}
+    top = valu if (valu and valu["frac"] >= hbm_frac) else hbm
     line = {
         "metric": "SQP iterations/sec (whole node), indy7 N=32 batch=1024, 1/2/4/8 MI355X",
         "value": value, "unit": "trajectory-SQP-iterations/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -222,9 +273,9 @@ def main():
                                "DEFAULT_SOLVER_PARAMS (max_pcg 200, pcg_tol 1e-4, rho 0.01), reset_dual+reset_rho per solve"
                                % (plant, N, B, world * B, iters),
                    "plant": plant, "knot_points": N, "batch_per_gpu": B, "global_batch": world * B, "sqp_iters_per_solve": int(iters),
-                   "mean_pcg_iters": float(st["pcg_iters_all"].mean()), "parallelism": "batch-sharded x%d, all_gather of iterates" % world},
-        "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic, "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_us": per_launch_us[dom],
+                   "mean_pcg_iters": float(st["pcg_iters_all"].mean()), "parallelism": "batch-sharded x%d, one packed all_gather of iterates + merits" % world},
+        "roofline": {"bound": "valu" if top is valu else "hbm", "kernel": dom, "achieved": top["achieved"], "peak": top["peak"], "unit": top["unit"],
+                     "frac": top["frac"], "traffic": traffic, "hbm": hbm, "valu": valu, "pmc": pmc, "avg_launch_us": per_launch_us[dom],
                      "stage_us_per_solve": {k: round(v, 1) for k, v in stage_acc.items()},
                      "kernels_per_sqp_iteration": sum(1 for k in launches if launches[k] and k != "merit") + 1,
                      "whole_iteration": {"algorithmic_bytes_per_traj_iter": iter_bytes,

@@ -890,7 +890,7 @@ GATO_DEV void schur_coop_pinv(float (*th)[2 * M::NQ], int l, float rho)
 }
 
 template<class M, int LPP>
-__global__ __launch_bounds__(256) void schurq_kernel(Buffers bf, int N, int B, float dt)
+__global__ __launch_bounds__(256) void schurq_kernel(Buffers bf, int N, int B, float dt, int write_right)
 {
     constexpr int NQ = M::NQ, NX = 2 * NQ, NU = NQ, RW = NX / LPP, BR = 3 * NX, BROW = 3 * NX * NX;
     if (bf.ctrl->done) return;
@@ -924,11 +924,13 @@ __global__ __launch_bounds__(256) void schurq_kernel(Buffers bf, int N, int B, f
             }
             store_vec<2 * NX, NX>(Sk1 + (size_t)(y0 + i) * BR, row);
         }
+        if (write_right) {  // the symmetric-storage PCG kernel forms the right blocks' products from the left blocks: no need to store them
 #pragma unroll
-        for (int x = 0; x < NX; x++) {
-            float* dst = Sk + (size_t)x * BR + 2 * NX + y0;
+            for (int x = 0; x < NX; x++) {
+                float* dst = Sk + (size_t)x * BR + 2 * NX + y0;
 #pragma unroll
-            for (int i = 0; i < RW; i++) dst[i] = phi[i][x];
+                for (int i = 0; i < RW; i++) dst[i] = phi[i][x];
+            }
         }
         float* gam = bf.gamma + (size_t)b * (N + 2) * NX + (size_t)(k + 2) * NX + y0;
 #pragma unroll
@@ -953,7 +955,7 @@ __global__ __launch_bounds__(256) void schurq_kernel(Buffers bf, int N, int B, f
 // (the lane's row of A, B, Q_{k+1}^-1) are fetched with lane-dependent ADDRESSES, everything else is loaded identically by the
 // group (one request).  The pivot row of each elimination step is broadcast inside the group with ds_bpermute (__shfl, width 16).
 template<class M>
-__global__ __launch_bounds__(256) void schur1_kernel(Buffers bf, int N, int B, float dt)
+__global__ __launch_bounds__(256) void schur1_kernel(Buffers bf, int N, int B, float dt, int write_right)
 {
     constexpr int NQ = M::NQ, NX = 2 * NQ, NU = NQ, BR = 3 * NX, BROW = 3 * NX * NX;
     static_assert(NX <= 16, "one group of 16 lanes per knot");
@@ -1069,8 +1071,10 @@ __global__ __launch_bounds__(256) void schur1_kernel(Buffers bf, int N, int B, f
             row[NX + x] = -th[x];
         }
         gstore_vec<2 * NX>(Sk1 + (size_t)y * BR, row);
+        if (write_right) {
 #pragma unroll
-        for (int x = 0; x < NX; x++) Sk[(size_t)x * BR + 2 * NX + y] = phi[x];  // right block of row k = phi^T
+            for (int x = 0; x < NX; x++) Sk[(size_t)x * BR + 2 * NX + y] = phi[x];  // right block of row k = phi^T
+        }
         bf.gamma[(size_t)b * (N + 2) * NX + (size_t)(k + 2) * NX + y] = gg;
     }
     // (theta_k + rho I_q)^-1 by Gauss-Jordan across the group (schur_linsys.cuh:150-164)
@@ -1113,7 +1117,7 @@ __global__ __launch_bounds__(256) void schur1_kernel(Buffers bf, int N, int B, f
 // stair preconditioner off-diagonals (formSchurSystemBatchedKernel2, schur_linsys.cuh:213-260): for k <= N-2
 //   res = Pm_{k+1} (phi_k Pm_k);  P^-1 row k+1 left = -res, row k right = -res^T   (Pm = the STORED, sign-carrying diagonals)
 template<class M>
-__global__ __launch_bounds__(64) void schur2_kernel(Buffers bf, int N, int B)
+__global__ __launch_bounds__(64) void schur2_kernel(Buffers bf, int N, int B, int write_right)
 {
     constexpr int NQ = M::NQ, NX = 2 * NQ, BR = 3 * NX, BROW = 3 * NX * NX;
     if (bf.ctrl->done) return;
@@ -1156,8 +1160,10 @@ __global__ __launch_bounds__(64) void schur2_kernel(Buffers bf, int N, int B)
             res[x] = -s;
         }
         store_vec<NX, NX>(Pk1 + y * BR, res);  // left of row k+1, row y
+        if (write_right) {
 #pragma unroll
-        for (int x = 0; x < NX; x++) Pkw[x * BR + 2 * NX + y] = res[x];  // right of row k: (row x, col y) = -res[y][x]
+            for (int x = 0; x < NX; x++) Pkw[x * BR + 2 * NX + y] = res[x];  // right of row k: (row x, col y) = -res[y][x]
+        }
     }
 }
 

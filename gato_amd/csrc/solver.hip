@@ -379,11 +379,15 @@ template<class M> static void launch_schur(GatoSolver* s, hipStream_t st, float 
     // (AGPR moves, a few spills) but still ahead of a lane-per-knot kernel pair: 185 vs 238 us per launch at C3
     const long probs = (long)s->B * s->N;
     constexpr int LPP = (M::NQ % 2 == 0) ? 4 : 2;
+    // right blocks (the transposes of the next block row's left blocks) are scattered 4-byte column writes: skipped when nobody reads them
+    // -- the symmetric-storage PCG kernel and the direct sweep work from the left blocks (stage tests ask for the complete matrices)
+    const int wr = (force_stair || !(s->pcg_choice == 7 || no_stair)) ? 1 : 0;
     if (s->schur_rowlane)   // one row per lane, 16 lanes per knot: the default for nq odd (GATO_SCHUR_ROWLANE)
-        hipLaunchKernelGGL((schur1_kernel<M>), dim3(cdiv(probs * 16, 256), 2), dim3(256), 0, st, s->bf, s->N, s->B, dt);
+        hipLaunchKernelGGL((schur1_kernel<M>), dim3(cdiv(probs * 16, 256), 2), dim3(256), 0, st, s->bf, s->N, s->B, dt, wr);
     else
-        hipLaunchKernelGGL((schurq_kernel<M, LPP>), dim3(cdiv(probs * LPP, 256), 2), dim3(256), 0, st, s->bf, s->N, s->B, dt);
-    if (!no_stair && (force_stair || !s->pcg_fold)) hipLaunchKernelGGL((schur2_kernel<M>), dim3(cdiv(probs, 64)), dim3(64), 0, st, s->bf, s->N, s->B);
+        hipLaunchKernelGGL((schurq_kernel<M, LPP>), dim3(cdiv(probs * LPP, 256), 2), dim3(256), 0, st, s->bf, s->N, s->B, dt, wr);
+    if (!no_stair && (force_stair || !s->pcg_fold))
+        hipLaunchKernelGGL((schur2_kernel<M>), dim3(cdiv(probs, 64)), dim3(64), 0, st, s->bf, s->N, s->B, wr);
 }
 
 template<class M, int RPT, int FORCE_WPS = 0> static void launch_pcgc(GatoSolver* s, hipStream_t st, int sqp_iter, int write_p)
