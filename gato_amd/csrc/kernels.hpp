@@ -1963,135 +1963,175 @@ __global__ __launch_bounds__(MAXT) void pcgs_kernel(Buffers bf, int N, int B, ui
 // LU sweep without pivoting (S is symmetric negative definite: -S is the Schur complement of the regularised KKT system):
 //     D_0 = main_0,  g_0 = gamma_0;      W_k = left_k D_{k-1}^-1,  D_k = main_k - W_k left_k^T,  g_k = gamma_k - W_k g_{k-1}   (k = 1 .. N-1)
 //     lambda_{N-1} = D_{N-1}^-1 g_{N-1};  lambda_k = D_k^-1 (g_k - left_{k+1}^T lambda_{k+1})                                     (k = N-2 .. 0)
-// (right_k = left_{k+1}^T exactly, see pcgs_kernel).  The recursion is serial in k -- this is the Riccati depth -- so a trajectory gets a
-// group of 16 lanes (lane r < nx owns row r of the running blocks; 4 trajectories per wavefront): D^-1 by Gauss-Jordan in the
-// arithmetic of block::invertMatrix's one-matrix form (linalg.cuh:364-519), pivot rows by ds_bpermute, operand blocks through LDS (the
-// workgroup is ONE wavefront, so its barriers cost no wait: they only order the lanes' LDS writes before the group's reads).  D_k^-1 is kept for the back substitution in the P^-1 buffer's
-// main blocks (the preconditioner is not formed in this mode).  Cost: N serial steps of ~2 nx^3 flops each, no iteration count --
-// the solve time no longer depends on the conditioning (rho), and lambda is exact to fp32 rounding instead of PCG's exit tolerance.
+// (right_k = left_{k+1}^T exactly, see pcgs_kernel).  The recursion is serial in k -- this is the Riccati depth -- so the lever is
+// the length of one step: ONE WAVEFRONT per trajectory, lane = (row r = lane / 4, column group cq = lane % 4) holds CW = ceil(nx / 4)
+// entries of row r of the running blocks (nx = 14 is padded to 16 with identity rows).  Operand blocks meet in LDS (stride 17: no bank
+// conflicts; the workgroup is one wavefront, so its barriers cost no wait and only order the lanes' LDS accesses); D^-1 by Gauss-Jordan
+// without pivoting (the scheme of block::invertMatrix, linalg.cuh:364-519, with v_rcp_f32 pivots) -- the pivot element through v_readlane,
+// the pivot row through ds_bpermute and the row multiplier through a DPP quad broadcast; the next block row's operands are fetched
+// from global memory while the current one is eliminated.  D_k^-1 is kept for the back substitution in the P^-1 buffer's main blocks
+// (the preconditioner is not formed in this mode).  Cost: N serial steps, no iteration count -- the solve time no longer depends on
+// the conditioning (rho), and lambda is exact to fp32 rounding instead of PCG's exit tolerance.
 // =========================================================================================================================
+template<int PC> GATO_DEV float quad_bcast(float v)  // lane PC of every quad
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), PC * 0x55, 0xf, 0xf, false));
+}
+GATO_DEV float quad_sum(float v)
+{
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));  // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));  // quad_perm [2,3,0,1]
+    return v;
+}
+// one Gauss-Jordan pivot of the distributed block: D[i] = entry (r, cq CW + i); P is a compile-time constant.  In place: column P of
+// the block becomes column P of the inverse (entry (r, P) is consumed as the row multiplier before it is overwritten).  1 / pivot is
+// v_rcp_f32 (1 ulp) -- this mode is not the reference's arithmetic, and the serial chain is what it pays for.
+template<int NX, int CW, int P> GATO_DEV void gj_quad_step(float* D, int r, int cq, int baddr)
+{
+    constexpr int PC = P / CW, PI = P % CW;   // column group and local index of column P
+    float prow[CW];
+#pragma unroll
+    for (int i = 0; i < CW; i++)              // row P, this lane's columns: lane 4 P + cq (ds_bpermute takes a byte address)
+        prow[i] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(baddr + 16 * P, __builtin_bit_cast(int, D[i])));
+    const float ppiv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, D[PI]), P * 4 + PC));  // entry (P, P)
+    const float pvInv = __builtin_amdgcn_rcpf(ppiv);
+    const float f = quad_bcast<PC>(D[PI]) * pvInv;                                                                    // entry (r, P) / pivot
+    const bool owner = (r == P);
+#pragma unroll
+    for (int i = 0; i < CW; i++) D[i] = owner ? D[i] * pvInv : __builtin_fmaf(-f, prow[i], D[i]);
+    D[PI] = (cq == PC) ? (owner ? pvInv : -f) : D[PI];
+    if constexpr (P + 1 < NX) gj_quad_step<NX, CW, P + 1>(D, r, cq, baddr);
+}
+
 template<class M>
 __global__ __launch_bounds__(64) void btd_direct_kernel(Buffers bf, int N, int B, int sqp_iter)
 {
-    constexpr int NQ = M::NQ, NX = 2 * NQ, BR = 3 * NX, BROW = 3 * NX * NX, LD = NX + 2;  // LD: LDS row stride (8-byte aligned rows, fewer conflicts)
-    __shared__ __attribute__((aligned(16))) float smem[4][3][NX * LD];
+    constexpr int NQ = M::NQ, NX = 2 * NQ, BR = 3 * NX, BROW = 3 * NX * NX;
+    constexpr int CW = (NX + 3) / 4, LD = 17;
+    __shared__ float sD[16 * LD], sL[16 * LD], sW[16 * LD], sv[32];
     if (bf.ctrl->done) return;
-    const int grp = threadIdx.x >> 4, r = threadIdx.x & 15;
-    const int b = blockIdx.x * 4 + grp;
-    const bool live = b < B;
-    const int bb = live ? b : B - 1;            // spare groups shadow the last trajectory and store nothing
-    const bool act = r < NX;
-    const int rr = act ? r : 0;
-    float* sA = smem[grp][0];                   // operand block (D^-1 of the previous block row, all rows)
-    float* sL = smem[grp][1];                   // left_k, all rows
-    float* sP = smem[grp][2];                   // pivot rows / vectors
-    const float* S = bf.S + (size_t)bb * N * BROW;
-    float* Dinv = bf.Pinv + (size_t)bb * N * BROW;
-    const float* gam = bf.gamma + (size_t)bb * (N + 2) * NX;
-    float* lam = bf.lambda + (size_t)bb * (N + 2) * NX;
-    const bool skip = bf.converged[bb] != 0;
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int r = lane >> 2, cq = lane & 3;
+    const int c0 = cq * CW;
+    const bool rowok = r < NX;
+    const float* S = bf.S + (size_t)b * N * BROW;
+    float* Dinv = bf.Pinv + (size_t)b * N * BROW;
+    const float* gam = bf.gamma + (size_t)b * (N + 2) * NX;
+    float* lam = bf.lambda + (size_t)b * (N + 2) * NX;
+    const bool skip = bf.converged[b] != 0;
 
     if (!skip) {
-        float Di[NX];        // row rr of D_{k-1}^-1
-        float g_prev = 0.f;  // entry rr of g_{k-1}
+        // entry (r, c0 + i) of a block of S (col offset `off`: 0 left, NX main); the padding of a 14 x 14 block to 16 x 16 is the identity
+        auto load_slice = [&](const float* base, int off, float* out, float diag) {
+#pragma unroll
+            for (int i = 0; i < CW; i++) {
+                const int c = c0 + i;
+                out[i] = (rowok && c < NX) ? base[(size_t)r * BR + off + c] : ((r == c) ? diag : 0.f);
+            }
+        };
+        float Di[CW];          // D_{k-1}^-1, this lane's entries
+        float g_prev = 0.f;    // g_{k-1}[r]
+        float Mn[CW], Ln[CW], Lrow[NX], gn;   // block row k's operands, fetched one step ahead
+        load_slice(S, NX, Mn, 1.0f);
+        gn = rowok ? gam[NX + r] : 0.f;
+#pragma unroll
+        for (int i = 0; i < CW; i++) Ln[i] = 0.f;
+#pragma unroll
+        for (int j = 0; j < NX; j++) Lrow[j] = 0.f;
         for (int k = 0; k < N; k++) {
-            const float* Sk = S + (size_t)k * BROW + (size_t)rr * BR;
-            float D[NX], Lr[NX], g;
-            gload_vec<NX>(D, Sk + NX);            // main_k, row rr
-            g = gam[(k + 1) * NX + rr];
+            float D[CW], Lc[CW], Lr[NX], g = gn;
+#pragma unroll
+            for (int i = 0; i < CW; i++) { D[i] = Mn[i]; Lc[i] = Ln[i]; }
+#pragma unroll
+            for (int j = 0; j < NX; j++) Lr[j] = Lrow[j];
+            if (k + 1 < N) {   // prefetch block row k+1 (its latency hides behind this step's elimination)
+                const float* Sn = S + (size_t)(k + 1) * BROW;
+                load_slice(Sn, NX, Mn, 1.0f);
+                load_slice(Sn, 0, Ln, 0.f);
+#pragma unroll
+                for (int j = 0; j < NX; j++) Lrow[j] = rowok ? Sn[(size_t)r * BR + j] : 0.f;
+                gn = rowok ? gam[(k + 2) * NX + r] : 0.f;
+            }
             if (k > 0) {
-                gload_vec<NX>(Lr, Sk);            // left_k, row rr
-                // publish D_{k-1}^-1 (rows), left_k (rows) and g_{k-1}
 #pragma unroll
-                for (int c = 0; c < NX; c++) {
-                    sA[rr * LD + c] = Di[c];
-                    sL[rr * LD + c] = Lr[c];
+                for (int i = 0; i < CW; i++) {
+                    sD[r * LD + c0 + i] = Di[i];
+                    sL[r * LD + c0 + i] = Lc[i];
                 }
-                sP[rr] = g_prev;
-                __syncthreads();  // one wavefront per workgroup: orders the lanes' LDS writes before the group's reads (no hardware wait)
-                // W row rr = left_k[rr][:] D_{k-1}^-1
-                float W[NX];
+                if (cq == 0) sv[r] = g_prev;
+                __syncthreads();
+                // W(r, own columns) = left_k(r, :) D_{k-1}^-1(:, own columns)
+                float W[CW];
 #pragma unroll
-                for (int c = 0; c < NX; c++) W[c] = 0.f;
+                for (int i = 0; i < CW; i++) W[i] = 0.f;
 #pragma unroll
                 for (int j = 0; j < NX; j++) {
 #pragma unroll
-                    for (int c = 0; c < NX; c++) W[c] = __builtin_fmaf(Lr[j], sA[j * LD + c], W[c]);
+                    for (int i = 0; i < CW; i++) W[i] = __builtin_fmaf(Lr[j], sD[j * LD + c0 + i], W[i]);
                 }
-                // D_k row rr = main_k[rr][:] - W[rr][:] left_k^T ;  g_k[rr] = gamma_k[rr] - W[rr][:] g_{k-1}
+#pragma unroll
+                for (int i = 0; i < CW; i++) sW[r * LD + c0 + i] = W[i];
+                __syncthreads();
+                // D_k(r, own columns) = main_k - W(r, :) left_k(own columns, :)^T ;  g_k(r) = gamma_k(r) - W(r, :) g_{k-1}
+                float Wr[NX];
+#pragma unroll
+                for (int j = 0; j < NX; j++) Wr[j] = sW[r * LD + j];
                 float wg = 0.f;
 #pragma unroll
-                for (int j = 0; j < NX; j++) wg = __builtin_fmaf(W[j], sP[j], wg);
+                for (int j = 0; j < NX; j++) wg = __builtin_fmaf(Wr[j], sv[j], wg);
                 g = g - wg;
 #pragma unroll
-                for (int c = 0; c < NX; c++) {
+                for (int i = 0; i < CW; i++) {
                     float acc = 0.f;
 #pragma unroll
-                    for (int j = 0; j < NX; j++) acc = __builtin_fmaf(W[j], sL[c * LD + j], acc);
-                    D[c] = D[c] - acc;
+                    for (int j = 0; j < NX; j++) acc = __builtin_fmaf(Wr[j], sL[(c0 + i) * LD + j], acc);
+                    D[i] = D[i] - acc;
                 }
+                __syncthreads();   // sD / sL / sW / sv are free for the next block row
             }
-            // D_k^-1 by Gauss-Jordan without pivoting, rows distributed over the lanes (in place: column p becomes column p of the inverse)
+            gj_quad_step<NX, CW, 0>(D, r, cq, cq * 4);
 #pragma unroll
-            for (int p = 0; p < NX; p++) {
-                float prow[NX];
-#pragma unroll
-                for (int c = 0; c < NX; c++) prow[c] = __shfl(D[c], p, 16);   // the pivot row from its owner lane (ds_bpermute, like schur1_kernel)
-                const float pvInv = 1.0f / prow[p];
-                const float f = D[p] * pvInv;
-                const bool owner = (rr == p);
-#pragma unroll
-                for (int c = 0; c < NX; c++) {
-                    float x, yv;
-                    if (c == p) {
-                        yv = 0.f - f;
-                        x = 1.0f;
-                    } else {
-                        x = D[c];
-                        yv = x - f * prow[c];
-                    }
-                    const float piv = x * pvInv;
-                    D[c] = owner ? piv : yv;
-                }
-            }
-#pragma unroll
-            for (int c = 0; c < NX; c++) Di[c] = D[c];
+            for (int i = 0; i < CW; i++) Di[i] = D[i];
             g_prev = g;
-            __syncthreads();  // the group is done reading sA / sL / sP before the next block row overwrites them
-            if (live && act) {
-                gstore_vec<NX>(Dinv + (size_t)k * BROW + (size_t)rr * BR + NX, Di);
-                lam[(k + 1) * NX + rr] = g;      // g_k parks in lambda until the back substitution overwrites it
+            if (rowok) {
+#pragma unroll
+                for (int i = 0; i < CW; i++)
+                    if (c0 + i < NX) Dinv[(size_t)k * BROW + (size_t)r * BR + NX + c0 + i] = Di[i];
+                if (cq == 0) lam[(k + 1) * NX + r] = g;   // g_k parks in lambda until the back substitution overwrites it
             }
         }
-        // back substitution; Di / g_prev hold block N-1
+        // back substitution; Di / g_prev hold block N-1.  Rows are split over the quad for the transposed product: group cq takes rows cq, cq+4, ...
         float lnext = 0.f;
         for (int k = N - 1; k >= 0; k--) {
             float rhs = g_prev;
             if (k < N - 1) {
-                // rhs = g_k - left_{k+1}^T lambda_{k+1}: entry rr = sum_i left_{k+1}[i][rr] lambda_{k+1}[i]
-                const float* Ln = S + (size_t)(k + 1) * BROW;
-                sP[rr] = lnext;
+                const float* Ln1 = S + (size_t)(k + 1) * BROW;   // left_{k+1}: entry (i, r)
+                if (cq == 0) sv[r] = lnext;
                 __syncthreads();
                 float acc = 0.f;
 #pragma unroll
-                for (int i = 0; i < NX; i++) acc = __builtin_fmaf(Ln[(size_t)i * BR + rr], sP[i], acc);
-                rhs = rhs - acc;
+                for (int q = 0; q < 4; q++) {
+                    const int i = cq + 4 * q;
+                    if (i < NX && rowok) acc = __builtin_fmaf(Ln1[(size_t)i * BR + r], sv[i], acc);
+                }
+                rhs = rhs - quad_sum(acc);
             }
-            sP[2 * NX + rr] = rhs;
+            if (cq == 0) sv[16 + r] = rhs;
             __syncthreads();
-            float l = 0.f;
+            float part = 0.f;
 #pragma unroll
-            for (int c = 0; c < NX; c++) l = __builtin_fmaf(Di[c], sP[2 * NX + c], l);
+            for (int i = 0; i < CW; i++) part = __builtin_fmaf(Di[i], (c0 + i < NX) ? sv[16 + c0 + i] : 0.f, part);
+            const float l = quad_sum(part);
             lnext = l;
             __syncthreads();
-            if (k > 0) {  // fetch block k-1 before lambda_k overwrites nothing it needs (g_{k-1} sits in lambda's slot k-1)
-                gload_vec<NX>(Di, Dinv + (size_t)(k - 1) * BROW + (size_t)rr * BR + NX);
-                g_prev = lam[k * NX + rr];
+            if (k > 0) {  // block k-1: D^-1 from the P^-1 buffer, g_{k-1} from lambda's slot k
+                load_slice(Dinv + (size_t)(k - 1) * BROW, NX, Di, 1.0f);
+                g_prev = rowok ? lam[k * NX + r] : 0.f;
             }
-            if (live && act) lam[(k + 1) * NX + rr] = l;
+            if (rowok && cq == 0) lam[(k + 1) * NX + r] = l;
         }
     }
-    if (live && r == 0) {
+    if (lane == 0) {
         // statistics: one "iteration"; a trajectory is never declared converged by the PCG rule (0 iterations, bsqp.cuh:153) in this mode
         const uint32_t it = skip ? 0u : 1u;
         bf.pcg_iters[b] = it;

@@ -446,10 +446,10 @@ template<class M> static void launch_pcg(GatoSolver* s, hipStream_t st, int sqp_
         }
     }
 }
-// opt-in direct solve of S lambda = gamma: 16 lanes per trajectory, 4 trajectories per 64-thread workgroup
+// opt-in direct solve of S lambda = gamma: one wavefront per trajectory
 template<class M> static void launch_direct(GatoSolver* s, hipStream_t st, int sqp_iter)
 {
-    hipLaunchKernelGGL((btd_direct_kernel<M>), dim3(cdiv(s->B, 4)), dim3(64), 0, st, s->bf, s->N, s->B, sqp_iter);
+    hipLaunchKernelGGL((btd_direct_kernel<M>), dim3(s->B), dim3(64), 0, st, s->bf, s->N, s->B, sqp_iter);
 }
 template<class M> static void launch_dz(GatoSolver* s, hipStream_t st, float dt, int sqp_iter)
 {
