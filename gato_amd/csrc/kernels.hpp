@@ -1763,43 +1763,53 @@ __global__ __launch_bounds__(MAXT) void pcgc_kernel(Buffers bf, int N, int B, ui
 //   left role : rows k nx + h nx/2 .. of left_k (S and P^-1): the row dot with v_{k-1} AND the transposed accumulate left_k^T v_k;
 //   main role : the same rows of main_k: the row dot with v_k; owns the vector entries x, r, p of its rows and does the PCG scalar work.
 // Per matrix-vector product: vector -> LDS | barrier | both roles work, the left role leaves its row partials and transposed partials in
-// LDS | barrier | the main role adds  main + left + (two halves of the transposed partial of block k+1).  Four rows of every thread's
+// LDS, every wavefront its share of v^T Mx v | barrier | the main role adds  main + left + (two halves of the transposed partial of
+// block k+1), everybody sums the wavefront shares: 4 barriers per PCG iteration.  Four rows of every thread's
 // P^-1 block live in LDS (float4 [nx][T], conflict-free) to stay under 256 registers.  Sums associate as (main + left) + t0 + t1; the
 // reference sums a row's 3 nx terms in sequence (linalg.cuh:174-260) -- the same fp32 freedom the other PCG kernels take (even / odd
 // pairs).  Needs the COMPLETE P^-1 in global memory (schur2_kernel) and N >= 16 (whole wavefronts).
 // One thread's HR x NX block times the window w (row dots) and -- TR -- its transpose times the
-// thread's own HR vector entries vo (tp[j] = sum_i Mt[i][j] vo[i]); every sum runs over its terms in index order.  The first NP rows of the block are parked in LDS as float4 chunks
+// thread's own HR vector entries vo (tp[j] = sum_i Mt[i][j] vo[i]).  The first NP rows of the block are parked in LDS as float4 chunks
 // [c][T] and streamed through four registers at a time; rows NP.. sit in Mt[0 .. HR-NP).
 template<int NX, int HR, int NP, bool TR>
 GATO_DEV void half_block(const float (*Mt)[NX], const float4* park, int T, const float* w, const float* vo, float* acc, float* tp)
 {
+    // packed FP32 (v_pk_fma_f32): row dots keep an (even, odd) pair of partial sums per row, the transposed accumulate advances two
+    // adjacent columns with the row's vector entry in both halves
+    f32x2 a2[HR], t2[TR ? NX / 2 : 1];
 #pragma unroll
-    for (int i = 0; i < HR; i++) acc[i] = 0.f;
+    for (int i = 0; i < HR; i++) a2[i] = f32x2{0.f, 0.f};
     if constexpr (TR) {
 #pragma unroll
-        for (int j = 0; j < NX; j++) tp[j] = 0.f;
+        for (int j = 0; j < NX / 2; j++) t2[j] = f32x2{0.f, 0.f};
     }
     if constexpr (NP > 0) {
 #pragma unroll
         for (int c = 0; c < (NP * NX) / 4; c++) {
             const float4 m4 = park[c * T];
-            const float m[4] = {m4.x, m4.y, m4.z, m4.w};
+            const f32x2 m[2] = {f32x2{m4.x, m4.y}, f32x2{m4.z, m4.w}};
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const int idx = 4 * c + q, i = idx / NX, j = idx % NX;
-                acc[i] = __builtin_fmaf(m[q], w[j], acc[i]);
-                if constexpr (TR) tp[j] = __builtin_fmaf(m[q], vo[i], tp[j]);
+            for (int q = 0; q < 2; q++) {
+                const int idx = 4 * c + 2 * q, i = idx / NX, j = idx % NX;   // NX even: a pair never straddles two rows
+                a2[i] = __builtin_elementwise_fma(m[q], f32x2{w[j], w[j + 1]}, a2[i]);
+                if constexpr (TR) t2[j / 2] = __builtin_elementwise_fma(m[q], f32x2{vo[i], vo[i]}, t2[j / 2]);
             }
         }
     }
 #pragma unroll
     for (int i = NP; i < HR; i++) {
 #pragma unroll
-        for (int j = 0; j < NX; j++) {
-            const float m = Mt[i - NP][j];
-            acc[i] = __builtin_fmaf(m, w[j], acc[i]);
-            if constexpr (TR) tp[j] = __builtin_fmaf(m, vo[i], tp[j]);
+        for (int j = 0; j < NX; j += 2) {
+            const f32x2 m = {Mt[i - NP][j], Mt[i - NP][j + 1]};
+            a2[i] = __builtin_elementwise_fma(m, f32x2{w[j], w[j + 1]}, a2[i]);
+            if constexpr (TR) t2[j / 2] = __builtin_elementwise_fma(m, f32x2{vo[i], vo[i]}, t2[j / 2]);
         }
+    }
+#pragma unroll
+    for (int i = 0; i < HR; i++) acc[i] = a2[i].x + a2[i].y;
+    if constexpr (TR) {
+#pragma unroll
+        for (int j = 0; j < NX / 2; j++) { tp[2 * j] = t2[j].x; tp[2 * j + 1] = t2[j].y; }
     }
 }
 
@@ -1822,7 +1832,7 @@ __global__ __launch_bounds__(MAXT) void pcgs_kernel(Buffers bf, int N, int B, ui
     float* rowbuf = partB + 16;                // [N nx]: the left-block part of every row's product
     float* tbuf = rowbuf + N * NX;             // [N + 1][2][nx]: transposed partials of block k, by row half; block N stays zero
     float4* park = reinterpret_cast<float4*>(tbuf + (N + 1) * 2 * NX) + t;  // [PF4][T]
-    if (t < 32) partA[t] = 0.f;
+    if (t < 32) partA[t] = 0.f;  // partA and partB are adjacent: slots of wavefronts the workgroup does not have stay zero
     const float abs_tol = 1e-6f;
     uint32_t iters = 0;
     const bool skip = bf.converged[b] != 0;    // pcg.cuh:29-32
@@ -1866,10 +1876,15 @@ __global__ __launch_bounds__(MAXT) void pcgs_kernel(Buffers bf, int N, int B, ui
 
         // out[i] = row r0 + i of Mx v for the main role; `vec` is the LDS copy of v (published by the caller's barrier); ISP: Mx = P^-1.
         // The roles are whole wavefronts, so each takes ONE branch per product and runs straight-line code inside it.
-        auto matvec = [&](const float* vec, const float* win, auto isp, float* out) {
+        // The product's barrier also carries the reduction of v^T Mx v, formed from the stored blocks only:
+        //     v^T Mx v = sum_k v_k^T main_k v_k + 2 v_k^T left_k v_{k-1}        (right_k = left_{k+1}^T exactly)
+        // -- the main role contributes its rows' v_k (main_k v_k), the left role 2 v_k (left_k v_{k-1}); the wavefront partials are written
+        // before the barrier and summed after it (4 barriers per PCG iteration instead of 6).  `vown`: the main role's rows of v.
+        auto matvec = [&](const float* vec, const float* win, auto isp, float* out, const float* vown, float* part) -> float {
             constexpr bool ISP = decltype(isp)::value;
             float acc[HR], w[NX];
             load_vec<NX, 2>(w, win);
+            float dotc = 0.f;
             if (!mainrole) {
                 float tp[NX], vo[HR];
 #pragma unroll
@@ -1878,10 +1893,17 @@ __global__ __launch_bounds__(MAXT) void pcgs_kernel(Buffers bf, int N, int B, ui
                 else half_block<NX, HR, 0, true>(Sm, nullptr, T, w, vo, acc, tp);
                 store_vec<NX, 2>(tbuf + (k * 2 + h) * NX, tp);
                 store_vec<HR, 1>(rowbuf + r0, acc);
+#pragma unroll
+                for (int i = 0; i < HR; i++) dotc = __builtin_fmaf(acc[i], vo[i], dotc);
+                dotc = 2.0f * dotc;
             } else {
                 if constexpr (ISP) half_block<NX, HR, NP, false>(Pm, park, T, w, nullptr, acc, nullptr);
                 else half_block<NX, HR, 0, false>(Sm, nullptr, T, w, nullptr, acc, nullptr);
+#pragma unroll
+                for (int i = 0; i < HR; i++) dotc = __builtin_fmaf(acc[i], vown[i], dotc);
             }
+            dotc = wave_sum(dotc);
+            if ((t & 63) == 0) part[t >> 6] = dotc;
             __syncthreads();
             if (mainrole) {
                 const float* t0 = tbuf + ((k + 1) * 2 + 0) * NX + h * HR;
@@ -1892,6 +1914,13 @@ __global__ __launch_bounds__(MAXT) void pcgs_kernel(Buffers bf, int N, int B, ui
 #pragma unroll
                 for (int i = 0; i < HR; i++) out[i] = 0.f;
             }
+            const float4 pa = reinterpret_cast<const float4*>(part)[0];
+            float tot = (pa.x + pa.y) + (pa.z + pa.w);
+            if constexpr (PARTS == 2) {
+                const float4 pb = reinterpret_cast<const float4*>(part)[1];
+                tot = tot + ((pb.x + pb.y) + (pb.z + pb.w));
+            }
+            return tot;
         };
         using yes = std::true_type;
         using no = std::false_type;
@@ -1899,30 +1928,21 @@ __global__ __launch_bounds__(MAXT) void pcgs_kernel(Buffers bf, int N, int B, ui
         if (mainrole) store_vec<HR, 1>(va + own, xv);
         __syncthreads();
         float acc[HR], zv[HR];
-        matvec(va, wina, no{}, acc);  // r = gamma - S x
+        (void)matvec(va, wina, no{}, acc, xv, partB);  // r = gamma - S x
 #pragma unroll
         for (int i = 0; i < HR; i++) rv[i] = gv[i] - acc[i];   // both are 0 in the left role
         if (mainrole) store_vec<HR, 1>(vb + own, rv);
         __syncthreads();
-        matvec(vb, winb, yes{}, zv);  // z = p = P^-1 r
-        float loc = 0.f;
+        float rho = matvec(vb, winb, yes{}, zv, rv, partA);  // z = p = P^-1 r, rho = r^T z
 #pragma unroll
-        for (int i = 0; i < HR; i++) {
-            pv[i] = zv[i];
-            loc += rv[i] * zv[i];
-        }
-        float rho = block_sum<PARTS>(loc, partA);
+        for (int i = 0; i < HR; i++) pv[i] = zv[i];
         if (!(fabsf(rho) < abs_tol)) {
             const float rho_init = fabsf(rho);
             for (uint32_t it = 0; it < max_iters; it++) {
                 iters++;
                 if (mainrole) store_vec<HR, 1>(va + own, pv);
                 __syncthreads();
-                matvec(va, wina, no{}, acc);  // A p
-                loc = 0.f;
-#pragma unroll
-                for (int i = 0; i < HR; i++) loc += pv[i] * acc[i];
-                const float pAp = block_sum<PARTS>(loc, partB);
+                const float pAp = matvec(va, wina, no{}, acc, pv, partB);  // A p and p^T A p
                 const float alpha = rho / pAp;
 #pragma unroll
                 for (int i = 0; i < HR; i++) {
@@ -1931,11 +1951,7 @@ __global__ __launch_bounds__(MAXT) void pcgs_kernel(Buffers bf, int N, int B, ui
                 }
                 if (mainrole) store_vec<HR, 1>(vb + own, rv);
                 __syncthreads();
-                matvec(vb, winb, yes{}, zv);  // z = P^-1 r
-                loc = 0.f;
-#pragma unroll
-                for (int i = 0; i < HR; i++) loc += rv[i] * zv[i];
-                const float rho_new = block_sum<PARTS>(loc, partA);
+                const float rho_new = matvec(vb, winb, yes{}, zv, rv, partA);  // z = P^-1 r and r^T z
                 if (fabsf(rho_new) < (abs_tol + eps * rho_init)) break;
                 const float beta = rho_new / rho;
                 rho = rho_new;

@@ -184,7 +184,7 @@ def test_iterate_parity_tight_pcg(plant, N, B):
     assert relscale(rg["initial_merit"], ro["initial_merit"]) < 1e-5
 
 
-@pytest.mark.parametrize("plant,N,B", [("indy7", 32, 16), ("iiwa14", 32, 8), ("iiwa14", 64, 4), ("iiwa14", 128, 4)])
+@pytest.mark.parametrize("plant,N,B", [("indy7", 32, 16), ("indy7", 64, 6), ("iiwa14", 32, 8), ("iiwa14", 64, 4), ("iiwa14", 128, 4)])
 def test_three_iterations_against_float64(plant, N, B):
     """Three free-running SQP iterations (rho adaptation on, lambda warm-started from iteration to iteration), PCG at its floor.
     The arbiter is the FLOAT64 build of the oracle: every trajectory of the HIP path must be as close to it as the fp32 oracle is
