@@ -18,7 +18,7 @@ SYMBOLS = [
     "gato_ee_pos", "gato_debug_read", "gato_debug_write", "gato_debug_stage", "gato_set_profiling", "gato_get_stage_times_us",
     "gato_last_error", "gato_version", "gato_reset_async", "gato_copy_final_merit_device", "gato_set_cost_weights_batch",
     "gato_synchronize", "gato_sim_forward_device", "gato_select_best", "gato_select_best_device",
-    "gato_plant_rk4", "gato_fk_placements", "gato_set_linear_solver",
+    "gato_plant_rk4", "gato_fk_placements", "gato_set_linear_solver", "gato_set_graph_mode",
 ]
 
 
@@ -77,6 +77,7 @@ def load():
         getattr(L, n).argtypes = [vp]
     L.gato_set_rho_adaptation.argtypes = [vp, C.c_int]
     L.gato_set_linear_solver.argtypes = [vp, C.c_int]
+    L.gato_set_graph_mode.argtypes = [vp, C.c_int]
     L.gato_sim_forward.argtypes = [vp, fp, fp, fp, C.c_float]
     L.gato_ee_pos.argtypes = [vp, fp, C.c_int, fp]
     L.gato_debug_read.argtypes = [vp, C.c_char_p, fp, C.c_uint64, C.POINTER(C.c_uint64)]
@@ -241,6 +242,10 @@ class NativeSolver:
 
     def set_rho_adaptation(self, enabled):
         _chk(load().gato_set_rho_adaptation(self.h, int(bool(enabled))))
+
+    def set_graph_mode(self, enabled):
+        """replay the host-buffer solve as a hipGraph (bit-identical; off by default)"""
+        _chk(load().gato_set_graph_mode(self.h, int(bool(enabled))))
 
     def set_linear_solver(self, mode):
         """"pcg" (the reference's solver) or "direct" (block-tridiagonal LU sweep; extension)"""

@@ -65,6 +65,13 @@ struct GatoSolver {
     // Schur complement is formed inside it.  Tuning overrides GATO_PCG_VARIANT / GATO_PCG_FOLD are read there, never in the solve loop.
     int pcg_choice, pcg_fold, pcg_fused;
     int linear_solver;  // 0: PCG (the reference's solver, pcg.cuh), 1: direct block-tridiagonal sweep (gato_set_linear_solver)
+    // optional hipGraph replay of the host-buffer solve (gato_set_graph_mode): the fixed launch sequence of one solve captured once per
+    // (dt, iteration count, mode switches) on the solver's own stream -- the buffers of gato_solve are the solver's own, so the kernel
+    // arguments never change between solves
+    int graph_mode;
+    hipStream_t own_stream;
+    hipGraphExec_t graph_exec;
+    float graph_dt; uint32_t graph_iters; int graph_adapt, graph_lin;
     float *d_sim_x, *d_sim_u, *d_sim_out;  // staging of sim_forward ([nx], [nu], [B][nx]), allocated with the solver
     float *d_sel_xm, *d_sel_err;           // gato_select_best: measured state [nx], per-hypothesis error [B]
     int32_t* d_sel_best;                   // [0] arg-min, [1] completion counter of the selection kernel
@@ -128,6 +135,9 @@ static int create_impl(GatoSolver* s, int plant, int N, int B, const GatoParams*
     s->cw = Costs{params->q_cost, params->qd_cost, params->u_cost, params->N_cost, params->q_lim_cost, params->vel_lim_cost, params->ctrl_lim_cost};
     s->adapt_rho = 1;
     s->linear_solver = 0;
+    s->graph_mode = getenv("GATO_GRAPH") ? atoi(getenv("GATO_GRAPH")) : 0;
+    s->own_stream = nullptr;
+    s->graph_exec = nullptr;
     s->fuse_schur = getenv("GATO_SCHUR_FUSED") ? atoi(getenv("GATO_SCHUR_FUSED")) : 1;
     s->fuse_step = getenv("GATO_STEP_FUSED") ? atoi(getenv("GATO_STEP_FUSED")) : 1;
     s->schur_rowlane = getenv("GATO_SCHUR_ROWLANE") ? atoi(getenv("GATO_SCHUR_ROWLANE")) : (s->nq % 2);
@@ -226,6 +236,8 @@ extern "C" int gato_destroy(GatoSolver* s)
     if (s->d_ee_q) (void)hipFree(s->d_ee_q);
     if (s->d_ee_out) (void)hipFree(s->d_ee_out);
     if (s->d_plant) (void)hipFree(s->d_plant);
+    if (s->graph_exec) (void)hipGraphExecDestroy(s->graph_exec);
+    if (s->own_stream) (void)hipStreamDestroy(s->own_stream);
     for (void* p : s->allocs) (void)hipFree(p);
     for (hipEvent_t e : s->events) (void)hipEventDestroy(e);
     delete s;
@@ -575,10 +587,36 @@ extern "C" int gato_solve(GatoSolver* s, float* xu, float dt, const float* x_s, 
     HIPCHK(hipMemcpy(s->d_xs_own, x_s, (size_t)s->B * s->nx * sizeof(float), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(s->d_ref_own, ref, (size_t)s->B * 6 * s->N * sizeof(float), hipMemcpyHostToDevice));
     HIPCHK(hipDeviceSynchronize());
+    const bool graph = s->graph_mode && !s->profiling;
+    if (graph) {
+        // (re)capture when something a kernel argument depends on changed; otherwise the instantiated graph is replayed as it is
+        if (!s->own_stream) HIPCHK(hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking));
+        const uint32_t iters = s->p.max_sqp_iters <= s->max_iters_alloc ? s->p.max_sqp_iters : s->max_iters_alloc;
+        if (!s->graph_exec || s->graph_dt != dt || s->graph_iters != iters || s->graph_adapt != s->adapt_rho || s->graph_lin != s->linear_solver) {
+            if (s->graph_exec) { (void)hipGraphExecDestroy(s->graph_exec); s->graph_exec = nullptr; }
+            hipGraph_t g = nullptr;
+            HIPCHK(hipStreamBeginCapture(s->own_stream, hipStreamCaptureModeThreadLocal));
+            const int rc_c = solve_dispatch(s, s->d_xu_own, dt, s->d_xs_own, s->d_ref_own, s->own_stream);
+            const hipError_t e_c = hipStreamEndCapture(s->own_stream, &g);
+            if (rc_c != GATO_OK) { if (g) (void)hipGraphDestroy(g); return rc_c; }
+            if (e_c != hipSuccess) return fail(GATO_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e_c));
+            const hipError_t e_i = hipGraphInstantiate(&s->graph_exec, g, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(g);
+            if (e_i != hipSuccess) { s->graph_exec = nullptr; return fail(GATO_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e_i)); }
+            s->graph_dt = dt; s->graph_iters = iters; s->graph_adapt = s->adapt_rho; s->graph_lin = s->linear_solver;
+        }
+        s->last_stream = s->own_stream;
+        s->last_stream_valid = true;
+    }
     auto t0 = std::chrono::high_resolution_clock::now();
-    int rc = solve_dispatch(s, s->d_xu_own, dt, s->d_xs_own, s->d_ref_own, nullptr);
-    if (rc != GATO_OK) return rc;
-    HIPCHK(hipDeviceSynchronize());
+    if (graph) {
+        HIPCHK(hipGraphLaunch(s->graph_exec, s->own_stream));
+        HIPCHK(hipStreamSynchronize(s->own_stream));
+    } else {
+        int rc = solve_dispatch(s, s->d_xu_own, dt, s->d_xs_own, s->d_ref_own, nullptr);
+        if (rc != GATO_OK) return rc;
+        HIPCHK(hipDeviceSynchronize());
+    }
     auto t1 = std::chrono::high_resolution_clock::now();
     if (sqp_time_us) *sqp_time_us = std::chrono::duration<double, std::micro>(t1 - t0).count();
     collect_profile(s);
@@ -731,6 +769,12 @@ extern "C" int gato_copy_final_merit_device(GatoSolver* s, float* d_out, void* s
     if (!s || !d_out) return fail(GATO_ERR_INVALID, "null argument");
     GUARD(s);
     HIPCHK(hipMemcpyAsync(d_out, s->bf.merit_cur, s->B * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return GATO_OK;
+}
+extern "C" int gato_set_graph_mode(GatoSolver* s, int enabled)
+{
+    if (!s) return fail(GATO_ERR_INVALID, "null solver");
+    s->graph_mode = enabled ? 1 : 0;
     return GATO_OK;
 }
 extern "C" int gato_set_linear_solver(GatoSolver* s, int mode)

@@ -106,6 +106,10 @@ int gato_set_rho_adaptation(GatoSolver* s, int enabled);
  * iteration.  GATO_LINSOLVE_PCG (default) is the reference's warm-started, stair-preconditioned PCG (gato/bsqp/kernels/pcg.cuh);
  * GATO_LINSOLVE_DIRECT is a block LU sweep over the block-tridiagonal system (no preconditioner, no iteration count, lambda exact to
  * fp32 rounding; pcg_iters reports 1 and no trajectory is ever flagged converged by the "0 PCG iterations" rule). */
+/* Replay the launch sequence of gato_solve (host-buffer form) as a hipGraph captured on first use (re-captured when dt, the iteration
+ * count or a mode switch changes).  Off by default: measured on MI355X the kernels of a solve already run back to back, so the replay
+ * changes the solve time by less than the run-to-run noise; results are bit-identical either way. */
+int gato_set_graph_mode(GatoSolver* s, int enabled);
 #define GATO_LINSOLVE_PCG 0
 #define GATO_LINSOLVE_DIRECT 1
 int gato_set_linear_solver(GatoSolver* s, int mode);

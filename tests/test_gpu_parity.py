@@ -712,3 +712,29 @@ def test_direct_block_tridiagonal_solver(plant, N, B):
     sp0 = NativeSolver(plant, N, B, dt=DT, **p4)
     sp0.set_f_ext_batch(pr["f_ext"])
     np.testing.assert_array_equal(r0["XU"], sp0.solve(xu, DT, xs, ref)["XU"])
+
+
+@pytest.mark.parametrize("plant,N,B", [("indy7", 32, 1), ("indy7", 32, 24), ("iiwa14", 128, 3)])
+def test_graph_replay_equals_eager_launches(plant, N, B):
+    """gato_set_graph_mode: the solve's launch sequence replayed as a hipGraph gives the bits of the eager launches, across repeated
+    solves (warm-started state lives in the solver's buffers, not in the graph), a re-capture (other dt) and a mode switch."""
+    from gato_amd._lib import NativeSolver
+    p = dict(DEFAULT_SOLVER_PARAMS, max_sqp_iters=3)
+    pr = fig8_problem(plant, N, B, f_ext_std=1.0)
+    out = {}
+    for graph in (0, 1):
+        s = NativeSolver(plant, N, B, dt=DT, **p)
+        s.set_f_ext_batch(pr["f_ext"])
+        s.set_graph_mode(graph)
+        seq = [s.solve(pr["xu"], DT, pr["x_s"], pr["ref"]), s.solve(pr["xu"], DT, pr["x_s"], pr["ref"])]   # second solve: warm lambda, adapted rho
+        seq.append(s.solve(pr["xu"], 0.02, pr["x_s"], pr["ref"]))                                            # other dt: re-capture
+        s.set_rho_adaptation(False)
+        s.reset_dual(); s.reset_rho()
+        seq.append(s.solve(pr["xu"], DT, pr["x_s"], pr["ref"]))
+        out[graph] = seq
+    for a, b in zip(out[0], out[1]):
+        np.testing.assert_array_equal(a["XU"], b["XU"])
+        np.testing.assert_array_equal(a["pcg_iters"], b["pcg_iters"])
+        np.testing.assert_array_equal(a["ls_step_size"], b["ls_step_size"])
+        np.testing.assert_array_equal(a["final_merit"], b["final_merit"])
+        assert b["sqp_time_us"] > 0

@@ -11,12 +11,14 @@ ap.add_argument("-N", type=int, default=32)
 ap.add_argument("--iters", type=int, nargs="+", default=[1, 5])
 ap.add_argument("--batches", type=int, nargs="+", default=[1, 2, 4, 8, 16, 32, 64])
 ap.add_argument("--reps", type=int, default=30)
+ap.add_argument("--graph", type=int, default=0)
 a = ap.parse_args()
 for it in a.iters:
     for B in a.batches:
         p = dict(DEFAULT_SOLVER_PARAMS, max_sqp_iters=it)
         pr = fig8_problem("indy7", a.N, B)
         s = NativeSolver("indy7", a.N, B, dt=0.01, **p)
+        s.set_graph_mode(a.graph)
         ts = []
         for r in range(a.reps):
             s.reset_dual(); s.reset_rho()
