@@ -83,9 +83,10 @@ class MPC_GATO:
         if self.batch_size == 1 or self.force_estimator is None:
             return
         force_batch = self.force_estimator.generate_batch()
+        placements = self._placements(q)                       # one forward-kinematics pass serves every hypothesis
         transformed = np.zeros_like(force_batch)
         for i in range(self.batch_size):
-            transformed[i, :] = self.transform_force_to_gato_frame(q, force_batch[i, :])
+            transformed[i, :] = self.transform_force_to_gato_frame(q, force_batch[i, :], placements)
         self.solver.set_f_ext_B(transformed)
 
     def evaluate_best_trajectory(self, x_last, u_last, x_curr, dt):
@@ -95,12 +96,15 @@ class MPC_GATO:
         self.force_estimator.update(best_id, errors, alpha=0.6, beta=0.5)
         return best_id
 
-    def transform_force_to_gato_frame(self, q, f_world):
+    def _placements(self, q):
+        from .. import _gato_ext
+        return _gato_ext.fk_placements(self.plant_type, np.asarray(q[: self.nq], np.float32))
+
+    def transform_force_to_gato_frame(self, q, f_world, placements=None):
         """mpc_controller.py:311-338 with the library's joint placements: the world wrench (linear f[:3], angular f[3:]) expressed in
         the last joint's frame, then `actInv` of the placement of that frame in its parent joint's frame; returned as
         [linear, angular] like the reference does."""
-        from .. import _gato_ext
-        R, p = _gato_ext.fk_placements(self.plant_type, np.asarray(q[: self.nq], np.float32))
+        R, p = self._placements(q) if placements is None else placements
         R_ee, p_ee, R_pj, p_pj = R[-1], p[-1], R[-2], p[-2]
         f_world = np.asarray(f_world, dtype=np.float64)
         lin, ang = _act_inv(R_ee, p_ee, f_world[:3], f_world[3:])

@@ -52,7 +52,7 @@ def test_transform_force_to_gato_frame_formula():
     lin, ang = wrench_in_frame(R[-1], p[-1], f[:3], f[3:])
     Rr, pr = R[-2].T @ R[-1], R[-2].T @ (p[-1] - p[-2])
     lin, ang = wrench_in_frame(Rr, pr, lin, ang)
-    got = MPC_GATO.transform_force_to_gato_frame(type("S", (), {"plant_type": "indy7", "nq": 6})(), q, f)
+    got = MPC_GATO.transform_force_to_gato_frame(None, q, f, placements=(R, p))
     np.testing.assert_allclose(got, np.concatenate([lin, ang]), atol=1e-12)
     assert abs(np.linalg.norm(got[:3]) - np.linalg.norm(f[:3])) < 1e-12                     # the force part is only rotated
 
