@@ -2324,9 +2324,11 @@ __global__ __launch_bounds__(128) void line_search_kernel(Buffers bf, int traj, 
 // dz + merit at the 8 step sizes + line search in ONE launch, a workgroup of 8 N lanes per trajectory (N <= 64): the step never
 // leaves the CU between the three (LDS), two launches and their cache write-back / invalidate are gone.  Lane t < N forms dz_t, then
 // lane t is (alpha index t / N, knot t % N) of the merit evaluation, then all lanes apply the chosen step.
-template<class M>
-__global__ __launch_bounds__(512) void step_kernel(Buffers bf, int N, int B, float dt, int sqp_iter, float thresh, int adapt_rho,
-                                                   const float* __restrict__ drho_init, int last_iter)
+// MAXT = 512 serves N <= 64 (the 8 merits of a trajectory are wave-level sums); MAXT = 1024 (N = 128: 128 registers per lane) sums a
+// merit over two wavefronts through LDS in the order of the stand-alone merit kernel.
+template<class M, int MAXT>
+__global__ __launch_bounds__(MAXT) void step_kernel(Buffers bf, int N, int B, float dt, int sqp_iter, float thresh, int adapt_rho,
+                                                    const float* __restrict__ drho_init, int last_iter)
 {
     constexpr int NQ = M::NQ, NX = 2 * NQ, NU = NQ, KS = NX + NU;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -2350,7 +2352,7 @@ __global__ __launch_bounds__(512) void step_kernel(Buffers bf, int N, int B, flo
         const int k = t % N, ai = t / N;
         const float alpha = (float)(1.0 / (double)(1 << ai));
         float m = merit_term<M>(bf, cw, N, b, k, alpha, 1, dzs, dt);
-        m = seg_sum(m, N, nullptr);  // N <= 64: inside one wavefront
+        m = seg_sum(m, N, mer + 8);  // N <= 64: inside one wavefront; N = 128: two wavefront partials per merit through LDS
         if (k == 0) {
             mer[ai] = m;
             bf.merit[(size_t)b * NUM_ALPHAS + ai] = m;

@@ -470,15 +470,19 @@ template<class M> static void launch_dz(GatoSolver* s, hipStream_t st, float dt,
 // dz + merit(8 alphas) + line search in one launch: a workgroup of 8 N lanes per trajectory
 static bool step_fused(const GatoSolver* s)
 {
-    return s->fuse_step && NUM_ALPHAS * s->N <= 512 && s->N <= 64;
+    return s->fuse_step && NUM_ALPHAS * s->N <= 1024;
 }
 // last: this is the final iteration of the solve -- the line search also puts drho back to its default (bsqp.cuh:189)
 template<class M> static void launch_step(GatoSolver* s, hipStream_t st, float dt, int sqp_iter, int last)
 {
     const float thresh = (float)s->B * s->p.solve_ratio;
-    const size_t lds = (size_t)(((s->traj + 3) & ~3) + 16) * sizeof(float);
-    hipLaunchKernelGGL((step_kernel<M>), dim3(s->B), dim3(NUM_ALPHAS * s->N), lds, st, s->bf, s->N, s->B, dt, sqp_iter, thresh,
-                       s->adapt_rho, (const float*)s->d_drho_init, last);
+    const size_t lds = (size_t)(((s->traj + 3) & ~3) + 8 + 16) * sizeof(float);   // the step, 8 merits, 16 wavefront partials
+    if (NUM_ALPHAS * s->N <= 512)
+        hipLaunchKernelGGL((step_kernel<M, 512>), dim3(s->B), dim3(NUM_ALPHAS * s->N), lds, st, s->bf, s->N, s->B, dt, sqp_iter, thresh,
+                           s->adapt_rho, (const float*)s->d_drho_init, last);
+    else
+        hipLaunchKernelGGL((step_kernel<M, 1024>), dim3(s->B), dim3(NUM_ALPHAS * s->N), lds, st, s->bf, s->N, s->B, dt, sqp_iter, thresh,
+                           s->adapt_rho, (const float*)s->d_drho_init, last);
 }
 static void launch_ls(GatoSolver* s, hipStream_t st, int sqp_iter, int last)
 {
