@@ -1813,8 +1813,13 @@ GATO_DEV void half_block(const float (*Mt)[NX], const float4* park, int T, const
     }
 }
 
-template<class M, int MAXT>
-__global__ __launch_bounds__(MAXT) void pcgs_kernel(Buffers bf, int N, int B, uint32_t max_iters, int sqp_iter)
+// FOLD: the stair off-diagonals of P^-1 (formSchurSystemBatchedKernel2, schur_linsys.cuh:213-260: left_k = -Pm_k (phi_{k-1} Pm_{k-1}) from the
+// STORED diagonal blocks Pm) are formed HERE instead of by schur2_kernel: the main role publishes its rows of Pm in LDS, the left role
+// -- which holds the rows of phi_{k-1} as its S block -- forms its rows of phi_{k-1} Pm_{k-1}, the two left threads of a block row
+// exchange them through LDS and each forms its rows of left_k.  Two passes over the block rows (the not-yet-used parking area holds
+// N/2 + 1 blocks of Pm and N/2 blocks of the intermediate product); the sums run in schur2_kernel's order.
+template<class M, int MAXT, bool FOLD>
+__global__ __launch_bounds__(MAXT, 2) void pcgs_kernel(Buffers bf, int N, int B, uint32_t max_iters, int sqp_iter)
 {
     constexpr int NQ = M::NQ, NX = 2 * NQ, HR = NX / 2, BR = 3 * NX, BROW = 3 * NX * NX;
     constexpr int NP = 4;                      // rows of the thread's P^-1 block parked in LDS
@@ -1849,15 +1854,80 @@ __global__ __launch_bounds__(MAXT) void pcgs_kernel(Buffers bf, int N, int B, ui
         {
             const float* Sg = bf.S + (size_t)b * N * BROW + (size_t)r0 * BR + (mainrole ? NX : 0);
             const float* Pg = bf.Pinv + (size_t)b * N * BROW + (size_t)r0 * BR + (mainrole ? NX : 0);
-            float prk[NP * NX];
+            float Pf[HR][NX];   // the thread's block of P^-1 before its first NP rows are parked
 #pragma unroll
             for (int i = 0; i < HR; i++) {
                 load_vec<NX, 2>(Sm[i], Sg + i * BR);
-                if (i < NP) load_vec<NX, 2>(prk + i * NX, Pg + i * BR);
-                else load_vec<NX, 2>(Pm[i - NP], Pg + i * BR);
+                if constexpr (FOLD) {
+                    if (mainrole) load_vec<NX, 2>(Pf[i], Pg + i * BR);
+                    else {
+#pragma unroll
+                        for (int c = 0; c < NX; c++) Pf[i][c] = 0.f;
+                    }
+                } else {
+                    load_vec<NX, 2>(Pf[i], Pg + i * BR);
+                }
+            }
+            if constexpr (FOLD) {
+                const int NB = N >> 1;                                  // block rows per pass
+                float* bufP = reinterpret_cast<float*>(park - t);       // [NB + 1][NX][NX]: Pm of block rows first-1 .. first+NB-1
+                float* bufX = bufP + (NB + 1) * NX * NX;                // [NB][NX][NX]: phi_{k-1} Pm_{k-1} of block rows first .. first+NB-1
+                for (int ps = 0; ps < 2; ps++) {
+                    const int first = ps * NB;
+                    const int slot = k - (first - 1);                   // this block row's slot in bufP
+                    if (mainrole && slot >= 0 && slot <= NB) {
+#pragma unroll
+                        for (int i = 0; i < HR; i++) store_vec<NX, 2>(bufP + (slot * NX + h * HR + i) * NX, Pf[i]);
+                    }
+                    __syncthreads();
+                    const bool mine = !mainrole && k >= first && k < first + NB && k >= 1;
+                    if (mine) {
+                        const float* Pk1 = bufP + (slot - 1) * NX * NX;  // Pm_{k-1}
+#pragma unroll
+                        for (int i = 0; i < HR; i++) if (opaque_true()) {   // a basic block per row: the scheduler must not hoist every row's LDS loads
+                            float x[NX];
+#pragma unroll
+                            for (int c = 0; c < NX; c++) x[c] = 0.f;
+#pragma unroll
+                            for (int j = 0; j < NX; j++) {
+                                float row[NX];
+                                load_vec<NX, 2>(row, Pk1 + j * NX);
+#pragma unroll
+                                for (int c = 0; c < NX; c++) x[c] += Sm[i][j] * row[c];
+                            }
+                            store_vec<NX, 2>(bufX + ((k - first) * NX + h * HR + i) * NX, x);
+                        }
+                    }
+                    __syncthreads();
+                    if (mine) {
+                        const float* Xk = bufX + (k - first) * NX * NX;
+#pragma unroll
+                        for (int i = 0; i < HR; i++) if (opaque_true()) {
+                            float tk[NX], res[NX];
+                            load_vec<NX, 2>(tk, bufP + (slot * NX + h * HR + i) * NX);   // row of Pm_k
+#pragma unroll
+                            for (int c = 0; c < NX; c++) res[c] = 0.f;
+#pragma unroll
+                            for (int j = 0; j < NX; j++) {
+                                float row[NX];
+                                load_vec<NX, 2>(row, Xk + j * NX);
+#pragma unroll
+                                for (int c = 0; c < NX; c++) res[c] += tk[j] * row[c];
+                            }
+#pragma unroll
+                            for (int c = 0; c < NX; c++) Pf[i][c] = -res[c];
+                        }
+                    }
+                    __syncthreads();   // bufP / bufX are free for the next pass, then for the parked rows
+                }
             }
 #pragma unroll
-            for (int c = 0; c < PF4; c++) park[c * T] = make_float4(prk[4 * c], prk[4 * c + 1], prk[4 * c + 2], prk[4 * c + 3]);
+            for (int c = 0; c < PF4; c++)
+                park[c * T] = make_float4((&Pf[0][0])[4 * c], (&Pf[0][0])[4 * c + 1], (&Pf[0][0])[4 * c + 2], (&Pf[0][0])[4 * c + 3]);
+#pragma unroll
+            for (int i = NP; i < HR; i++)
+#pragma unroll
+                for (int c = 0; c < NX; c++) Pm[i - NP][c] = Pf[i][c];
         }
         float xv[HR], rv[HR], pv[HR], gv[HR];
 #pragma unroll

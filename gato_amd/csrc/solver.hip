@@ -332,14 +332,23 @@ static size_t pcgs_lds(const GatoSolver* s)
 }
 template<class M> static bool pcgs_grant(const GatoSolver* s)
 {
-    if (4 * s->N <= 256) return grant_lds(reinterpret_cast<const void*>(&pcgs_kernel<M, 256>), pcgs_lds(s));
-    return grant_lds(reinterpret_cast<const void*>(&pcgs_kernel<M, 512>), pcgs_lds(s));
+    if (4 * s->N <= 256)
+        return grant_lds(reinterpret_cast<const void*>(&pcgs_kernel<M, 256, false>), pcgs_lds(s)) &&
+               grant_lds(reinterpret_cast<const void*>(&pcgs_kernel<M, 256, true>), pcgs_lds(s));
+    return grant_lds(reinterpret_cast<const void*>(&pcgs_kernel<M, 512, false>), pcgs_lds(s)) &&
+           grant_lds(reinterpret_cast<const void*>(&pcgs_kernel<M, 512, true>), pcgs_lds(s));
 }
-template<class M> static void launch_pcgs(GatoSolver* s, hipStream_t st, int sqp_iter)
+// fold: the kernel forms the stair off-diagonals itself (solve path); otherwise it reads the complete P^-1 (stage tests, GATO_PCG_FOLD=0)
+template<class M> static void launch_pcgs(GatoSolver* s, hipStream_t st, int sqp_iter, bool fold)
 {
     const int T = 4 * s->N;
-    if (T <= 256) hipLaunchKernelGGL((pcgs_kernel<M, 256>), dim3(s->B), dim3(T), pcgs_lds(s), st, s->bf, s->N, s->B, s->p.max_pcg_iters, sqp_iter);
-    else hipLaunchKernelGGL((pcgs_kernel<M, 512>), dim3(s->B), dim3(T), pcgs_lds(s), st, s->bf, s->N, s->B, s->p.max_pcg_iters, sqp_iter);
+    if (T <= 256) {
+        if (fold) hipLaunchKernelGGL((pcgs_kernel<M, 256, true>), dim3(s->B), dim3(T), pcgs_lds(s), st, s->bf, s->N, s->B, s->p.max_pcg_iters, sqp_iter);
+        else hipLaunchKernelGGL((pcgs_kernel<M, 256, false>), dim3(s->B), dim3(T), pcgs_lds(s), st, s->bf, s->N, s->B, s->p.max_pcg_iters, sqp_iter);
+    } else {
+        if (fold) hipLaunchKernelGGL((pcgs_kernel<M, 512, true>), dim3(s->B), dim3(T), pcgs_lds(s), st, s->bf, s->N, s->B, s->p.max_pcg_iters, sqp_iter);
+        else hipLaunchKernelGGL((pcgs_kernel<M, 512, false>), dim3(s->B), dim3(T), pcgs_lds(s), st, s->bf, s->N, s->B, s->p.max_pcg_iters, sqp_iter);
+    }
 }
 
 template<class M> static int plan_pcg(GatoSolver* s)
@@ -361,7 +370,7 @@ template<class M> static int plan_pcg(GatoSolver* s)
     s->pcg_choice = choice;
     // the kernel that will run forms the stair off-diagonals itself when the two fold buffers + the vectors fit one CU's LDS and the
     // runtime grants them; otherwise schur2_kernel is launched (launch_schur) and the kernel reads the complete P^-1
-    bool fold = fold_wanted && choice != 0 && choice != 7 && pcg_vec_lds(s) + pcg_fold_lds(s) <= 150 * 1024;
+    bool fold = fold_wanted && choice != 0 && (choice == 7 || pcg_vec_lds(s) + pcg_fold_lds(s) <= 150 * 1024);  // pcgs folds inside its own LDS
     if (fold) {
         switch (choice) {
             case 4: fold = pcgc_grant_fold<M, 2, 3>(s); break;
@@ -370,6 +379,7 @@ template<class M> static int plan_pcg(GatoSolver* s)
             case 2: fold = pcgc_grant_fold<M, 3>(s); break;
             case 3: fold = pcgc_grant_fold<M, 2>(s); break;
             case 1: fold = pcgc_grant_fold<M, 6>(s); break;
+            case 7: break;   // granted with the kernel (pcgs_grant)
         }
     }
     s->pcg_fold = fold ? 1 : 0;
@@ -438,7 +448,7 @@ template<class M> static void launch_pcg(GatoSolver* s, hipStream_t st, int sqp_
         case 2: launch_pcgc<M, 3>(s, st, sqp_iter, write_p); return;
         case 3: launch_pcgc<M, 2>(s, st, sqp_iter, write_p); return;
         case 1: launch_pcgc<M, 6>(s, st, sqp_iter, write_p); return;
-        case 7: launch_pcgs<M>(s, st, sqp_iter); return;
+        case 7: launch_pcgs<M>(s, st, sqp_iter, s->pcg_fold != 0); return;
         default: break;
     }
     const int T1 = ((rows + 63) / 64) * 64;
