@@ -181,16 +181,33 @@ def main():
     xu0 = torch.from_numpy(pr["xu"]).to(dev)
     x_s = torch.from_numpy(pr["x_s"]).to(dev)
     ref = torch.from_numpy(pr["ref"]).to(dev)
-    pk = PackedResults(B, solver.traj, world, dev)  # [B*TRAJ iterates | B merits], solved in place, gathered by ONE collective
-    xu, merit = pk.xu, pk.merit
-    stream = torch.cuda.current_stream().cuda_stream
+    # two packed result buffers [B*TRAJ iterates | B merits], solved in place and gathered by ONE collective each: the gather of solve n
+    # runs on a communication stream while solve n+1 iterates in the other buffer (collectives overlapped with compute on separate HIP
+    # streams); a buffer is reused only after the gather that read it has completed (per-buffer events)
+    pks = [PackedResults(B, solver.traj, world, dev) for _ in range(2)]
+    main = torch.cuda.current_stream()
+    stream = main.cuda_stream
+    comm = torch.cuda.Stream() if world > 1 else None
+    done = [torch.cuda.Event(), torch.cuda.Event()]
+    used = [False, False]
+    count = [0]
 
     def step():
+        j = count[0] & 1
+        count[0] += 1
+        pk = pks[j]
+        if used[j]:
+            main.wait_event(done[j])            # the gather that last read this buffer
         solver.reset_async(True, True, stream)  # reset_dual() + reset_rho(), stream-ordered
-        xu.copy_(xu0)
-        solver.solve_device(xu.data_ptr(), dt, x_s.data_ptr(), ref.data_ptr(), stream)
-        solver.copy_final_merit_device(merit.data_ptr(), stream)
-        pk.all_gather()                         # iterates + costs: (B x TRAJ + B) fp32 per rank over xGMI (no-op on one GPU)
+        pk.xu.copy_(xu0)
+        solver.solve_device(pk.xu.data_ptr(), dt, x_s.data_ptr(), ref.data_ptr(), stream)
+        solver.copy_final_merit_device(pk.merit.data_ptr(), stream)
+        if comm is not None:
+            comm.wait_stream(main)
+            with torch.cuda.stream(comm):
+                pk.all_gather()                 # iterates + costs: (B x TRAJ + B) fp32 per rank over xGMI
+            done[j].record(comm)
+            used[j] = True
 
     def sync():
         if world > 1:
@@ -273,7 +290,7 @@ def main():
                                "DEFAULT_SOLVER_PARAMS (max_pcg 200, pcg_tol 1e-4, rho 0.01), reset_dual+reset_rho per solve"
                                % (plant, N, B, world * B, iters),
                    "plant": plant, "knot_points": N, "batch_per_gpu": B, "global_batch": world * B, "sqp_iters_per_solve": int(iters),
-                   "mean_pcg_iters": float(st["pcg_iters_all"].mean()), "parallelism": "batch-sharded x%d, one packed all_gather of iterates + merits" % world},
+                   "mean_pcg_iters": float(st["pcg_iters_all"].mean()), "parallelism": "batch-sharded x%d, one packed all_gather of iterates + merits per solve, overlapped with the next solve" % world},
         "roofline": {"bound": "valu" if top is valu else "hbm", "kernel": dom, "achieved": top["achieved"], "peak": top["peak"], "unit": top["unit"],
                      "frac": top["frac"], "traffic": traffic, "hbm": hbm, "valu": valu, "pmc": pmc, "avg_launch_us": per_launch_us[dom],
                      "stage_us_per_solve": {k: round(v, 1) for k, v in stage_acc.items()},

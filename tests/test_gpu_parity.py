@@ -738,3 +738,27 @@ def test_graph_replay_equals_eager_launches(plant, N, B):
         np.testing.assert_array_equal(a["ls_step_size"], b["ls_step_size"])
         np.testing.assert_array_equal(a["final_merit"], b["final_merit"])
         assert b["sqp_time_us"] > 0
+
+
+@pytest.mark.parametrize("plant,N,B", [("indy7", 256, 2), ("iiwa14", 256, 1), ("iiwa14", 4, 3), ("indy7", 16, 1025)])
+def test_corner_sizes(plant, N, B):
+    """The ends of the supported range (horizons 4 and 256: the streaming PCG kernel and the un-fused step path; a batch that is not a
+    multiple of anything): one iteration against the oracle at PCG's floor, then a default 3-iteration solve that must descend."""
+    from gato_amd._lib import NativeSolver
+    from oracle.oracle import OracleSolver
+    Bo = min(B, 3)
+    nat, orc, pr = make(plant, N, Bo, 1.0, max_sqp_iters=1, **TIGHT)
+    rg = nat.solve(pr["xu"], DT, pr["x_s"], pr["ref"])
+    ro = orc.solve(pr["xu"], DT, pr["x_s"], pr["ref"])
+    np.testing.assert_array_equal(rg["ls_step_size"], ro["ls_step_size"])
+    assert traj_err(rg["XU"], ro["XU"]).max() < 5e-4, traj_err(rg["XU"], ro["XU"])
+    pb = fig8_problem(plant, N, B, f_ext_std=1.0)
+    big = NativeSolver(plant, N, B, dt=DT, **dict(DEFAULT_SOLVER_PARAMS, max_sqp_iters=3))
+    big.set_f_ext_batch(pb["f_ext"])
+    out = big.solve(pb["xu"], DT, pb["x_s"], pb["ref"])
+    assert out["iters_done"] == 3 and np.all(np.isfinite(out["XU"])) and np.all(out["final_merit"] < out["initial_merit"])
+    if B > 3:   # the first rows of the big batch equal the small batch's rows solved alone (batch independence at an odd size)
+        small = NativeSolver(plant, N, 3, dt=DT, **dict(DEFAULT_SOLVER_PARAMS, max_sqp_iters=3))
+        small.set_f_ext_batch(pb["f_ext"][:3])
+        o3 = small.solve(pb["xu"][:3], DT, pb["x_s"][:3], pb["ref"][:3])
+        np.testing.assert_array_equal(o3["XU"], out["XU"][:3])
