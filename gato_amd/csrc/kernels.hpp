@@ -951,85 +951,109 @@ __global__ __launch_bounds__(256) void schurq_kernel(Buffers bf, int N, int B, f
 
 // ---- one ROW per lane: groups of 16 lanes (nx of them active) per (b,k) ----------------------------------------------------------
 // For nx = 14 (iiwa14) the 4-lane split does not exist and 2 lanes x 7 rows need ~400 registers.  Here lane l < nx owns row l of
-// phi_k, theta_k and (theta_k + rho I_q)^-1: ~200 registers, 16 x the wavefronts of a lane-per-knot kernel.  Row-dependent inputs
-// (the lane's row of A, B, Q_{k+1}^-1) are fetched with lane-dependent ADDRESSES, everything else is loaded identically by the
-// group (one request).  The pivot row of each elimination step is broadcast inside the group with ds_bpermute (__shfl, width 16).
-template<class M>
+// phi_k, theta_k and (theta_k + rho I_q)^-1, 16 x the wavefronts of a lane-per-knot kernel.  Everything a knot's rows read -- D_k, the
+// inverses of knots k and k+1, q, r, c -- is fetched ONCE by the group into an LDS record with independent, coalesced loads (one
+// memory latency; the first version chained six dependent fetch phases at two wavefronts per SIMD and spent 80 us per launch on
+// them) and the rows are formed from LDS: no 147-register copy of D, 4+ wavefronts per SIMD.  The arithmetic and its order are
+// unchanged.  The pivot row of each elimination step is broadcast inside the group with ds_bpermute (__shfl, width 16).
+// ROW0: the launch also forms the Q_0 rows (grid.y = 2; stage tests) -- in a solve the assembly kernel's cost task forms them, and the
+// lane-per-trajectory code (a 7 x 7 Gauss-Jordan in registers) does not set this kernel's register count.
+template<class M, bool ROW0>
 __global__ __launch_bounds__(256) void schur1_kernel(Buffers bf, int N, int B, float dt, int write_right)
 {
-    constexpr int NQ = M::NQ, NX = 2 * NQ, NU = NQ, BR = 3 * NX, BROW = 3 * NX * NX;
+    constexpr int NQ = M::NQ, NX = 2 * NQ, NU = NQ, BR = 3 * NX, BROW = 3 * NX * NX, ND = 3 * NQ * NQ, NQQ = NQ * NQ;
     static_assert(NX <= 16, "one group of 16 lanes per knot");
+    // record of one knot: D | Qi | di | ri | q | r | Qi1 | di1 | q1 | c1   (Qi1 .. c1: knot k+1)
+    constexpr int O_QI = ND, O_DI = O_QI + NQQ, O_RI = O_DI + NQ, O_Q = O_RI + NU, O_R = O_Q + NX, O_QI1 = O_R + NU, O_DI1 = O_QI1 + NQQ,
+                  O_Q1 = O_DI1 + NQ, O_C1 = O_Q1 + NX, REC = O_C1 + NX + 1;   // + 1: odd stride, the 16 records of a workgroup spread over the banks
+    __shared__ float recs[16 * REC];
     if (bf.ctrl->done) return;
-    if (blockIdx.y == 1) {  // the Q_0 rows: one lane per trajectory
-        const int b = blockIdx.x * blockDim.x + threadIdx.x;
-        if (b >= B) return;
-        schur_row0<M>(bf, N, b, bf.rho[b], bf.S + (size_t)b * N * BROW, bf.Pinv + (size_t)b * N * BROW, bf.gamma + (size_t)b * (N + 2) * NX);
-        return;
+    if constexpr (ROW0) {
+        if (blockIdx.y == 1) {  // the Q_0 rows: one lane per trajectory
+            const int b = blockIdx.x * blockDim.x + threadIdx.x;
+            if (b >= B) return;
+            schur_row0<M>(bf, N, b, bf.rho[b], bf.S + (size_t)b * N * BROW, bf.Pinv + (size_t)b * N * BROW, bf.gamma + (size_t)b * (N + 2) * NX);
+            return;
+        }
     }
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     const int l = threadIdx.x & 15;
     const int pidx = g >> 4;
     const int k = pidx % N, b = pidx / N;
-    if (b >= B || k == N - 1) return;  // whole groups are in or out
+    const bool live = b < B && k < N - 1;   // whole groups are in or out; they still reach the barrier
+    const size_t bk = live ? (size_t)b * N + k : 0;
+    float* R = recs + (threadIdx.x >> 4) * REC;
+    if (live) {
+        auto fetch = [&](int off, const float* src, int cnt) {
+            for (int i = l; i < cnt; i += 16) R[off + i] = src[i];
+        };
+        fetch(0, bf.D + bk * ND, ND);
+        fetch(O_QI, bf.Qqi + bk * NQQ, NQQ);
+        fetch(O_DI, bf.Qdi + bk * NQ, NQ);
+        fetch(O_RI, bf.Rdi + bk * NU, NU);
+        fetch(O_Q, bf.q + bk * NX, NX);
+        fetch(O_R, bf.r + bk * NU, NU);
+        fetch(O_QI1, bf.Qqi + (bk + 1) * NQQ, NQQ);
+        fetch(O_DI1, bf.Qdi + (bk + 1) * NQ, NQ);
+        fetch(O_Q1, bf.q + (bk + 1) * NX, NX);
+        fetch(O_C1, bf.c + (bk + 1) * NX, NX);
+    }
+    __syncthreads();
+    if (!live) return;
     const bool act = l < NX;
     const int y = act ? l : 0;         // the 16 - nx spare lanes shadow row 0 and store nothing
     const bool upper = y < NQ;         // row in the q half
     const int rm = upper ? y : y - NQ;
-    const size_t bk = (size_t)b * N + k;
     const float h2 = half_dt_sq(dt);
     const float coef = upper ? h2 : dt;
-    const float* Dg = bf.D + bk * 3 * NQ * NQ;
+    const float* Dm = R;
 
     float Ar[NX], Bri[NU], phi[NX], th[NX], gg;
     {
         // own row of A_k (A_elem with a lane-dependent row) and of B_k R_k^-1
-        float ri[NU];
-        gload_vec<NU>(ri, bf.Rdi + bk * NU);
 #pragma unroll
         for (int c = 0; c < NX; c++) {
-            const float d = Dg[c * NQ + rm];
+            const float d = Dm[c * NQ + rm];
             float v0 = (c == y) ? 1.0f : 0.f;
             if (c >= NQ) v0 = (upper && c - NQ == y) ? dt : v0;
             Ar[c] = v0 + coef * d;
         }
 #pragma unroll
-        for (int c = 0; c < NU; c++) Bri[c] = (coef * Dg[2 * NQ * NQ + c * NQ + rm]) * ri[c];
+        for (int c = 0; c < NU; c++) Bri[c] = (coef * Dm[2 * NQQ + c * NQ + rm]) * R[O_RI + c];
     }
-    if (opaque_true()) {
-        float Qi[NQ * NQ], di[NQ];
-        gload_vec<NQ * NQ>(Qi, bf.Qqi + bk * NQ * NQ);
-        gload_vec<NQ>(di, bf.Qdi + bk * NQ);
+    {
 #pragma unroll
         for (int c = 0; c < NQ; c++) {
             float sacc = 0.f;
 #pragma unroll
-            for (int j = 0; j < NQ; j++) sacc += Ar[j] * Qi[c * NQ + j];
+            for (int j = 0; j < NQ; j++) sacc += Ar[j] * R[O_QI + c * NQ + j];
             phi[c] = sacc;
-            phi[NQ + c] = Ar[NQ + c] * di[c];
+            phi[NQ + c] = Ar[NQ + c] * R[O_DI + c];
         }
     }
     // own row of Q_{k+1}^-1: tq (q half, zero in qd-half lanes) and the single diagonal entry td (qd half)
     float tq[NQ], td;
     {
-        const float* Q1 = bf.Qqi + (bk + 1) * NQ * NQ;
 #pragma unroll
         for (int x = 0; x < NQ; x++) {
-            const float v = Q1[x * NQ + rm];
+            const float v = R[O_QI1 + x * NQ + rm];
             tq[x] = upper ? v : 0.f;
         }
-        const float dv = bf.Qdi[(bk + 1) * NQ + rm];
+        const float dv = R[O_DI1 + rm];
         td = upper ? 0.f : dv;
     }
-    if (opaque_true()) {
-        float Dm[3 * NQ * NQ];
-        gload_vec<3 * NQ * NQ>(Dm, Dg);
+    {
 #pragma unroll
         for (int x = 0; x < NX; x++) {
+            // the record pointer is laundered per column: otherwise the optimiser keeps every D entry it has seen in a register for the
+            // columns that reuse it (a 147-register copy of D again, two wavefronts per SIMD); re-reading LDS costs less than that
+            const float* Dx = Dm;
+            asm volatile("" : "+v"(Dx));
             float sacc = 0.f, s2 = 0.f;
 #pragma unroll
-            for (int j = 0; j < NX; j++) sacc += phi[j] * A_elem<NQ>(Dm, x, j, dt, h2);
+            for (int j = 0; j < NX; j++) sacc += phi[j] * A_elem<NQ>(Dx, x, j, dt, h2);
 #pragma unroll
-            for (int j = 0; j < NU; j++) s2 += Bri[j] * B_elem<NQ>(Dm, x, j, dt, h2);
+            for (int j = 0; j < NU; j++) s2 += Bri[j] * B_elem<NQ>(Dx, x, j, dt, h2);
             float t;
             if (x < NQ) t = tq[x];
             else t = (x - NQ == rm) ? td : 0.f;
@@ -1038,25 +1062,21 @@ __global__ __launch_bounds__(256) void schur1_kernel(Buffers bf, int N, int B, f
             th[x] = t;
         }
     }
-    if (opaque_true()) {
-        float qk[NX], qk1[NX], rk[NU];
-        gload_vec<NX>(qk, bf.q + bk * NX);
-        gload_vec<NX>(qk1, bf.q + (bk + 1) * NX);
-        gload_vec<NU>(rk, bf.r + bk * NU);
-        const float cy = bf.c[(bk + 1) * NX + y], qy = bf.q[(bk + 1) * NX + y];
+    {
+        const float cy = R[O_C1 + y], qy = R[O_Q1 + y];
         float g1 = -1.0f * cy;
         float sq = 0.f;
 #pragma unroll
-        for (int j = 0; j < NQ; j++) sq += tq[j] * qk1[j];
+        for (int j = 0; j < NQ; j++) sq += tq[j] * R[O_Q1 + j];
         const float sd = td * qy;
         g1 += upper ? sq : sd;
         float sacc = 0.f;
 #pragma unroll
-        for (int j = 0; j < NX; j++) sacc += phi[j] * qk[j];
+        for (int j = 0; j < NX; j++) sacc += phi[j] * R[O_Q + j];
         g1 += -sacc;
         sacc = 0.f;
 #pragma unroll
-        for (int j = 0; j < NU; j++) sacc += Bri[j] * rk[j];
+        for (int j = 0; j < NU; j++) sacc += Bri[j] * R[O_R + j];
         g1 += -sacc;
         gg = -1.0f * g1;
     }

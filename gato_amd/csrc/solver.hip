@@ -395,7 +395,8 @@ template<class M> static int plan_pcg(GatoSolver* s)
 }
 static int plan_pcg_dispatch(GatoSolver* s) { return s->plant == GATO_PLANT_INDY7 ? plan_pcg<Indy7>(s) : plan_pcg<Iiwa14>(s); }
 
-template<class M> static void launch_schur(GatoSolver* s, hipStream_t st, float dt, bool force_stair = false, bool no_stair = false)
+// row0_done: the Q_0 rows were formed by the assembly kernel's cost task (launch_kkt with row0 = 1: every solve path)
+template<class M> static void launch_schur(GatoSolver* s, hipStream_t st, float dt, bool force_stair = false, bool no_stair = false, bool row0_done = false)
 {
     // lanes per (b,k): 4 with rows 3l..3l+2 (indy7); nq odd (iiwa14) divides evenly only into 2 x 7 rows -- heavier on registers
     // (AGPR moves, a few spills) but still ahead of a lane-per-knot kernel pair: 185 vs 238 us per launch at C3
@@ -404,9 +405,10 @@ template<class M> static void launch_schur(GatoSolver* s, hipStream_t st, float 
     // right blocks (the transposes of the next block row's left blocks) are scattered 4-byte column writes: skipped when nobody reads them
     // -- the symmetric-storage PCG kernel and the direct sweep work from the left blocks (stage tests ask for the complete matrices)
     const int wr = (force_stair || !(s->pcg_choice == 7 || no_stair)) ? 1 : 0;
-    if (s->schur_rowlane)   // one row per lane, 16 lanes per knot: the default for nq odd (GATO_SCHUR_ROWLANE)
-        hipLaunchKernelGGL((schur1_kernel<M>), dim3(cdiv(probs * 16, 256), 2), dim3(256), 0, st, s->bf, s->N, s->B, dt, wr);
-    else
+    if (s->schur_rowlane) {  // one row per lane, 16 lanes per knot: the default for nq odd (GATO_SCHUR_ROWLANE)
+        if (row0_done) hipLaunchKernelGGL((schur1_kernel<M, false>), dim3(cdiv(probs * 16, 256), 1), dim3(256), 0, st, s->bf, s->N, s->B, dt, wr);
+        else hipLaunchKernelGGL((schur1_kernel<M, true>), dim3(cdiv(probs * 16, 256), 2), dim3(256), 0, st, s->bf, s->N, s->B, dt, wr);
+    } else
         hipLaunchKernelGGL((schurq_kernel<M, LPP>), dim3(cdiv(probs * LPP, 256), 2), dim3(256), 0, st, s->bf, s->N, s->B, dt, wr);
     if (!no_stair && (force_stair || !s->pcg_fold))
         hipLaunchKernelGGL((schur2_kernel<M>), dim3(cdiv(probs, 64)), dim3(64), 0, st, s->bf, s->N, s->B, wr);
@@ -532,16 +534,17 @@ template<class M> static int solve_impl(GatoSolver* s, float* d_xu, float dt, co
     for (uint32_t it = 0; it < iters; it++) {
         const bool direct = s->linear_solver == 1;
         const bool fused = s->pcg_fused != 0 && !direct;
-        launch_kkt<M>(s, st, dt, (int)it, fused ? 1 : 0);
+        const bool row0 = fused || s->schur_rowlane;   // the Q_0 rows by the assembly kernel's cost task (always, where the Schur kernel allows it)
+        launch_kkt<M>(s, st, dt, (int)it, row0 ? 1 : 0);
         mark(s, st, ST_KKT, ei);
         if (direct) {
-            launch_schur<M>(s, st, dt, false, true);   // S and gamma only: no preconditioner in this mode
+            launch_schur<M>(s, st, dt, false, true, row0);   // S and gamma only: no preconditioner in this mode
             mark(s, st, ST_SCHUR, ei);
             launch_direct<M>(s, st, (int)it);
         } else if (fused) {
             launch_pcg_fused<M>(s, st, dt, (int)it);
         } else {
-            launch_schur<M>(s, st, dt);
+            launch_schur<M>(s, st, dt, false, false, row0);
             mark(s, st, ST_SCHUR, ei);
             launch_pcg<M>(s, st, (int)it);
         }
