@@ -1,3 +1,7 @@
+#!/usr/bin/env python3
+"""Teacher-forced trace (runs on the MI355X box): ten SQP iterations, each started on the HIP path, the fp32 oracle and the float64 oracle
+from the fp32 oracle's state; prints per iteration the PCG counts, the dz errors of the three pairs and the steps.  Produced
+profiles/r02_teacher_forced_indy7_{floor,default}.log:  python tools/teacher_forced_trace.py indy7 32 8 1 | 0"""
 import sys, os, json
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
