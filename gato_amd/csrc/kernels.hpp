@@ -13,8 +13,11 @@
 //     (nx = 14) and N > 64;
 //   * the SQP loop has no host round trip: convergence counting and the solve_ratio early exit run on the device (Ctrl).
 //
-// Global layouts are trajectory-major like the reference's (linalg.cuh:545-672) so xu / x_s / ref / lambda / gamma (and S / P^-1 where
-// they are materialised) are byte-compatible with its buffers; KKT blocks are stored COMPACT:
+// Global layouts are trajectory-major like the reference's (linalg.cuh:545-672) so xu / x_s / ref / lambda / gamma are byte-compatible
+// with its buffers.  S / P^-1, where they are materialised, are BLOCK-major: [b][k][left | main | right][row][col] -- a block is nx^2
+// contiguous floats, so the lanes that own the rows of one block read and write one contiguous run (the reference's row-major block rows
+// [row][left | main | right] put a block's rows 3 nx floats apart: schur2 moved 4x its bytes; gato_debug_read converts for the tests).
+// KKT blocks are stored COMPACT:
 //   D    [b][k][3 nq^2]   = [dqdd/dq | dqdd/dqd | M^-1] col-major nq x 3nq   (A_k, B_k are functions of D and dt: A_elem/B_elem)
 //   Qq   [b][k][nq^2], Qd [b][k][nq]   Q_k = blkdiag(Qq, diag(Qd))   (the cost Hessian has no other non-zeros, indy7_plant.cuh:375-408)
 //   Rd   [b][k][nu]                     R_k = diag(Rd)
@@ -616,7 +619,7 @@ __global__ __launch_bounds__(64 * ((M::NQ + 1) / 2 + 1), 2) void kkt_kernel(Buff
 template<class M>
 GATO_DEV void schur_row0_regs(float* Qq, const float* Qd, const float* q0, const float* c0, float rho, float* S, float* P, float* gam)
 {
-    constexpr int NQ = M::NQ, NX = 2 * NQ, BR = 3 * NX;
+    constexpr int NQ = M::NQ, NX = 2 * NQ, BLK = NX * NX;
     {
         // the Q_0 row (schur_linsys.cuh:166-210): P^-1 row 0 = -(Q_0 + rho I_q), S row 0 = -(Q_0 + rho I_q)^-1, gamma_0 = c_0 - Q_0^-1 q_0
         float Qi[NQ * NQ];
@@ -632,7 +635,7 @@ GATO_DEV void schur_row0_regs(float* Qq, const float* Qd, const float* q0, const
                 else if (x == y) v = -Qd[y - NQ];
                 row[x] = v;
             }
-            store_vec<NX, NX>(P + y * BR + NX, row);
+            store_vec<NX, NX>(P + BLK + y * NX, row);
         }
         gj_inverse<NQ, false>(Qq);
 #pragma unroll
@@ -650,7 +653,7 @@ GATO_DEV void schur_row0_regs(float* Qq, const float* Qd, const float* q0, const
                 else if (x == y) v = -di[y - NQ];
                 row[x] = v;
             }
-            store_vec<NX, NX>(S + y * BR + NX, row);
+            store_vec<NX, NX>(S + BLK + y * NX, row);
         }
         float g0[NX];
 #pragma unroll
@@ -892,7 +895,7 @@ GATO_DEV void schur_coop_pinv(float (*th)[2 * M::NQ], int l, float rho)
 template<class M, int LPP>
 __global__ __launch_bounds__(256) void schurq_kernel(Buffers bf, int N, int B, float dt, int write_right)
 {
-    constexpr int NQ = M::NQ, NX = 2 * NQ, NU = NQ, RW = NX / LPP, BR = 3 * NX, BROW = 3 * NX * NX;
+    constexpr int NQ = M::NQ, NX = 2 * NQ, NU = NQ, RW = NX / LPP, BLK = NX * NX, BROW = 3 * NX * NX;
     if (bf.ctrl->done) return;
     if (blockIdx.y == 1) {  // the Q_0 rows: one lane per trajectory
         const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -916,18 +919,16 @@ __global__ __launch_bounds__(256) void schurq_kernel(Buffers bf, int N, int B, f
         // consecutive entries of every transposed row
 #pragma unroll
         for (int i = 0; i < RW; i++) {
-            float row[2 * NX];
+            float row[NX];
 #pragma unroll
-            for (int x = 0; x < NX; x++) {
-                row[x] = phi[i][x];
-                row[NX + x] = -th[i][x];
-            }
-            store_vec<2 * NX, NX>(Sk1 + (size_t)(y0 + i) * BR, row);
+            for (int x = 0; x < NX; x++) row[x] = -th[i][x];
+            store_vec<NX, NX>(Sk1 + (size_t)(y0 + i) * NX, phi[i]);
+            store_vec<NX, NX>(Sk1 + BLK + (size_t)(y0 + i) * NX, row);
         }
         if (write_right) {  // the symmetric-storage PCG kernel forms the right blocks' products from the left blocks: no need to store them
 #pragma unroll
             for (int x = 0; x < NX; x++) {
-                float* dst = Sk + (size_t)x * BR + 2 * NX + y0;
+                float* dst = Sk + 2 * BLK + (size_t)x * NX + y0;
 #pragma unroll
                 for (int i = 0; i < RW; i++) dst[i] = phi[i][x];
             }
@@ -944,7 +945,7 @@ __global__ __launch_bounds__(256) void schurq_kernel(Buffers bf, int N, int B, f
             float row[NX];
 #pragma unroll
             for (int x = 0; x < NX; x++) row[x] = -th[i][x];
-            store_vec<NX, NX>(Pk1 + (size_t)(y0 + i) * BR + NX, row);
+            store_vec<NX, NX>(Pk1 + BLK + (size_t)(y0 + i) * NX, row);
         }
     }
 }
@@ -961,7 +962,7 @@ __global__ __launch_bounds__(256) void schurq_kernel(Buffers bf, int N, int B, f
 template<class M, bool ROW0>
 __global__ __launch_bounds__(256) void schur1_kernel(Buffers bf, int N, int B, float dt, int write_right)
 {
-    constexpr int NQ = M::NQ, NX = 2 * NQ, NU = NQ, BR = 3 * NX, BROW = 3 * NX * NX, ND = 3 * NQ * NQ, NQQ = NQ * NQ;
+    constexpr int NQ = M::NQ, NX = 2 * NQ, NU = NQ, BLK = NX * NX, BROW = 3 * NX * NX, ND = 3 * NQ * NQ, NQQ = NQ * NQ;
     static_assert(NX <= 16, "one group of 16 lanes per knot");
     // record of one knot: D | Qi | di | ri | q | r | Qi1 | di1 | q1 | c1   (Qi1 .. c1: knot k+1)
     constexpr int O_QI = ND, O_DI = O_QI + NQQ, O_RI = O_DI + NQ, O_Q = O_RI + NU, O_R = O_Q + NX, O_QI1 = O_R + NU, O_DI1 = O_QI1 + NQQ,
@@ -1084,16 +1085,14 @@ __global__ __launch_bounds__(256) void schur1_kernel(Buffers bf, int N, int B, f
     if (act) {
         float* Sk = S + (size_t)k * BROW;
         float* Sk1 = S + (size_t)(k + 1) * BROW;
-        float row[2 * NX];
+        float row[NX];
 #pragma unroll
-        for (int x = 0; x < NX; x++) {
-            row[x] = phi[x];
-            row[NX + x] = -th[x];
-        }
-        gstore_vec<2 * NX>(Sk1 + (size_t)y * BR, row);
+        for (int x = 0; x < NX; x++) row[x] = -th[x];
+        gstore_vec<NX>(Sk1 + (size_t)y * NX, phi);          // the group's 14 rows of a block: one contiguous run
+        gstore_vec<NX>(Sk1 + BLK + (size_t)y * NX, row);
         if (write_right) {
 #pragma unroll
-            for (int x = 0; x < NX; x++) Sk[(size_t)x * BR + 2 * NX + y] = phi[x];  // right block of row k = phi^T
+            for (int x = 0; x < NX; x++) Sk[2 * BLK + (size_t)x * NX + y] = phi[x];  // right block of row k = phi^T
         }
         bf.gamma[(size_t)b * (N + 2) * NX + (size_t)(k + 2) * NX + y] = gg;
     }
@@ -1129,7 +1128,7 @@ __global__ __launch_bounds__(256) void schur1_kernel(Buffers bf, int N, int B, f
             float row[NX];
 #pragma unroll
             for (int x = 0; x < NX; x++) row[x] = -th[x];
-            gstore_vec<NX>(Pk1 + (size_t)y * BR + NX, row);
+            gstore_vec<NX>(Pk1 + BLK + (size_t)y * NX, row);
         }
     }
 }
@@ -1139,7 +1138,7 @@ __global__ __launch_bounds__(256) void schur1_kernel(Buffers bf, int N, int B, f
 template<class M>
 __global__ __launch_bounds__(64) void schur2_kernel(Buffers bf, int N, int B, int write_right)
 {
-    constexpr int NQ = M::NQ, NX = 2 * NQ, BR = 3 * NX, BROW = 3 * NX * NX;
+    constexpr int NQ = M::NQ, NX = 2 * NQ, BLK = NX * NX, BROW = 3 * NX * NX;
     if (bf.ctrl->done) return;
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     const int k = g % N, b = g / N;
@@ -1153,11 +1152,11 @@ __global__ __launch_bounds__(64) void schur2_kernel(Buffers bf, int N, int B, in
     {
         float tkm1[NX][NX];
 #pragma unroll
-        for (int y = 0; y < NX; y++) load_vec<NX, NX>(tkm1[y], Pk + y * BR + NX);
+        for (int y = 0; y < NX; y++) load_vec<NX, NX>(tkm1[y], Pk + BLK + y * NX);
 #pragma unroll
         for (int y = 0; y < NX; y++) {
             float ph[NX];
-            load_vec<NX, NX>(ph, Sk1 + y * BR);
+            load_vec<NX, NX>(ph, Sk1 + y * NX);
 #pragma unroll
             for (int x = 0; x < NX; x++) {
                 float s = 0.f;
@@ -1171,7 +1170,7 @@ __global__ __launch_bounds__(64) void schur2_kernel(Buffers bf, int N, int B, in
 #pragma unroll
     for (int y = 0; y < NX; y++) {
         float tk[NX], res[NX];
-        load_vec<NX, NX>(tk, Pk1 + y * BR + NX);
+        load_vec<NX, NX>(tk, Pk1 + BLK + y * NX);
 #pragma unroll
         for (int x = 0; x < NX; x++) {
             float s = 0.f;
@@ -1179,10 +1178,10 @@ __global__ __launch_bounds__(64) void schur2_kernel(Buffers bf, int N, int B, in
             for (int j = 0; j < NX; j++) s += tk[j] * scr[j][x];
             res[x] = -s;
         }
-        store_vec<NX, NX>(Pk1 + y * BR, res);  // left of row k+1, row y
+        store_vec<NX, NX>(Pk1 + y * NX, res);  // left of row k+1, row y
         if (write_right) {
 #pragma unroll
-            for (int x = 0; x < NX; x++) Pkw[x * BR + 2 * NX + y] = res[x];  // right of row k: (row x, col y) = -res[y][x]
+            for (int x = 0; x < NX; x++) Pkw[2 * BLK + x * NX + y] = res[x];  // right of row k: (row x, col y) = -res[y][x]
         }
     }
 }
@@ -1254,6 +1253,16 @@ template<int PARTS = 4> GATO_DEV float block_sum(float v, float* part)
     return r + (((c.x + c.y) + (c.z + c.w)) + ((d.x + d.y) + (d.z + d.w)));
 }
 
+// row `y` of block row `k` of a block-major matrix as the 3 nx floats [left | main | right] the row dots work on
+template<int NX> GATO_DEV void load_btd_row(float* dst, const float* __restrict__ Mb, int k, int y)
+{
+    constexpr int BLK = NX * NX;
+    const float* base = Mb + (size_t)k * 3 * BLK + (size_t)y * NX;
+    load_vec<NX, NX>(dst, base);
+    load_vec<NX, NX>(dst + NX, base + BLK);
+    load_vec<NX, NX>(dst + 2 * NX, base + 2 * BLK);
+}
+
 // RPT rows per thread; STREAM = false keeps the thread's S / P^-1 rows in registers, true re-reads them from global memory
 // (L2 / Infinity Cache) for systems that do not fit one CU's register file (iiwa14 N = 128: 602 KB); MAXT = launch bound.
 template<class M, int RPT, bool STREAM, int MAXT>
@@ -1285,25 +1294,24 @@ __global__ __launch_bounds__(MAXT) void pcg_kernel(Buffers bf, int N, int B, uin
         float Srow[RPT][RB], Prow[RPT][RB], xv[RPT], rv[RPT], pv[RPT], zv[RPT];
         int row[RPT];
         bool have[RPT];
-        const float* Sg[RPT];
-        const float* Pg[RPT];
+        int rk[RPT], ry[RPT];   // block row and row inside it
 #pragma unroll
         for (int u = 0; u < RPT; u++) {
             row[u] = threadIdx.x + u * T;
             have[u] = row[u] < nrows;
             const int rr = have[u] ? row[u] : 0;
-            Sg[u] = S + (size_t)rr * BR;
-            Pg[u] = P + (size_t)rr * BR;
+            rk[u] = rr / NX;
+            ry[u] = rr - rk[u] * NX;
             if constexpr (!STREAM) {
-                load_vec<BR, NX>(Srow[u], Sg[u]);
-                load_vec<BR, NX>(Prow[u], Pg[u]);
+                load_btd_row<NX>(Srow[u], S, rk[u], ry[u]);
+                load_btd_row<NX>(Prow[u], P, rk[u], ry[u]);
             }
             xv[u] = have[u] ? lam[NX + rr] : 0.f;
         }
         auto sdot = [&](int u, const float* win) -> float {
             if constexpr (STREAM) {
                 float tmp[BR];
-                load_vec<BR, NX>(tmp, Sg[u]);
+                load_btd_row<NX>(tmp, S, rk[u], ry[u]);
                 return row_dot<NX>(tmp, win);
             } else {
                 return row_dot<NX>(Srow[u], win);
@@ -1312,7 +1320,7 @@ __global__ __launch_bounds__(MAXT) void pcg_kernel(Buffers bf, int N, int B, uin
         auto pdot = [&](int u, const float* win) -> float {
             if constexpr (STREAM) {
                 float tmp[BR];
-                load_vec<BR, NX>(tmp, Pg[u]);
+                load_btd_row<NX>(tmp, P, rk[u], ry[u]);
                 return row_dot<NX>(tmp, win);
             } else {
                 return row_dot<NX>(Prow[u], win);
@@ -1559,16 +1567,17 @@ __global__ __launch_bounds__(MAXT) void pcgc_kernel(Buffers bf, int N, int B, ui
             if (opaque_true()) {
                 // block row 0 (the Q_0 rows, written by the assembly kernel's cost task): rows 3l.. are read by every thread (one
                 // cached request per row) and kept by the first group only
-                const float* S = bf.S + (size_t)b * N * BROW + (size_t)(RPT * l) * BR;
-                const float* P = bf.Pinv + (size_t)b * N * BROW + (size_t)(RPT * l) * BR;
+                constexpr int BLK = NX * NX;
+                const float* S = bf.S + (size_t)b * N * BROW + BLK + (size_t)(RPT * l) * NX;      // main block of block row 0
+                const float* P = bf.Pinv + (size_t)b * N * BROW + BLK + (size_t)(RPT * l) * NX;
                 const bool first = have && kb == 0;
                 float g0[RPT];
                 load_vec<RPT, RPT>(g0, gam + NX + RPT * l);
 #pragma unroll
                 for (int u = 0; u < RPT; u++) {
                     float sm[NX], pm[NX];
-                    load_vec<NX, NX>(sm, S + u * BR + NX);
-                    load_vec<NX, NX>(pm, P + u * BR + NX);
+                    load_vec<NX, NX>(sm, S + u * NX);
+                    load_vec<NX, NX>(pm, P + u * NX);
 #pragma unroll
                     for (int x = 0; x < NX; x++) {
                         Srow[u][x] = first ? 0.f : Srow[u][x];
@@ -1593,13 +1602,14 @@ __global__ __launch_bounds__(MAXT) void pcgc_kernel(Buffers bf, int N, int B, ui
                 for (int x = 0; x < NX; x++) Srow[u][2 * NX + x] = (have && kb + 1 < N) ? bufA[((kb + 1) * NX + x) * NX + i0 + u] : 0.f;
             __syncthreads();  // bufA is reused by the stair fold below
         } else {
-            const float* S = bf.S + (size_t)b * N * BROW + (size_t)rr * BR;
-            const float* P = bf.Pinv + (size_t)b * N * BROW + (size_t)rr * BR;
+            const float* S = bf.S + (size_t)b * N * BROW;
+            const float* P = bf.Pinv + (size_t)b * N * BROW;
+            const int y0 = rr - kb * NX;   // the thread's first row inside block row kb
 #pragma unroll
             for (int u = 0; u < RPT; u++) {
-                load_vec<BR, NX>(Srow[u], S + u * BR);
-                if constexpr (FOLD) load_vec<NX, NX>(&Prow[u][NX], P + u * BR + NX);  // off-diagonals are formed below
-                else load_vec<BR, NX>(Prow[u], P + u * BR);
+                load_btd_row<NX>(Srow[u], S, kb, y0 + u);
+                if constexpr (FOLD) load_vec<NX, NX>(&Prow[u][NX], P + (size_t)kb * BROW + NX * NX + (size_t)(y0 + u) * NX);  // off-diagonals are formed below
+                else load_btd_row<NX>(Prow[u], P, kb, y0 + u);
             }
             load_vec<RPT, RPT>(xv, lam + NX + rr);
             load_vec<RPT, RPT>(gv, gam + NX + rr);
@@ -1673,11 +1683,11 @@ __global__ __launch_bounds__(MAXT) void pcgc_kernel(Buffers bf, int N, int B, ui
                         Prow[u][2 * NX + x] = (kb + 1 < N) ? bufA[((kb + 1) * NX + x) * NX + i0 + u] : 0.f;  // right = left_{k+1}^T
                 }
                 if (write_p) {
-                    float* Pg = bf.Pinv + (size_t)b * N * BROW + (size_t)rr * BR;
+                    float* Pg = bf.Pinv + (size_t)b * N * BROW + (size_t)kb * BROW + (size_t)i0 * NX;
 #pragma unroll
                     for (int u = 0; u < RPT; u++) {
-                        store_vec<NX, 2>(Pg + u * BR, &Prow[u][0]);
-                        store_vec<NX, 2>(Pg + u * BR + 2 * NX, &Prow[u][2 * NX]);
+                        store_vec<NX, 2>(Pg + u * NX, &Prow[u][0]);                      // left block
+                        store_vec<NX, 2>(Pg + 2 * NX * NX + u * NX, &Prow[u][2 * NX]);   // right block
                     }
                 }
             }
@@ -1872,20 +1882,22 @@ __global__ __launch_bounds__(MAXT, 2) void pcgs_kernel(Buffers bf, int N, int B,
         float* lam = bf.lambda + (size_t)b * vecp;
         float Sm[HR][NX], Pm[HR - NP][NX];
         {
-            const float* Sg = bf.S + (size_t)b * N * BROW + (size_t)r0 * BR + (mainrole ? NX : 0);
-            const float* Pg = bf.Pinv + (size_t)b * N * BROW + (size_t)r0 * BR + (mainrole ? NX : 0);
+            // rows h HR .. of the left or the main block of block row k: HR nx contiguous floats in the block-major storage
+            const size_t boff = (size_t)b * N * BROW + (size_t)k * BROW + (mainrole ? NX * NX : 0) + (size_t)h * HR * NX;
+            const float* Sg = bf.S + boff;
+            const float* Pg = bf.Pinv + boff;
             float Pf[HR][NX];   // the thread's block of P^-1 before its first NP rows are parked
 #pragma unroll
             for (int i = 0; i < HR; i++) {
-                load_vec<NX, 2>(Sm[i], Sg + i * BR);
+                load_vec<NX, 2>(Sm[i], Sg + i * NX);
                 if constexpr (FOLD) {
-                    if (mainrole) load_vec<NX, 2>(Pf[i], Pg + i * BR);
+                    if (mainrole) load_vec<NX, 2>(Pf[i], Pg + i * NX);
                     else {
 #pragma unroll
                         for (int c = 0; c < NX; c++) Pf[i][c] = 0.f;
                     }
                 } else {
-                    load_vec<NX, 2>(Pf[i], Pg + i * BR);
+                    load_vec<NX, 2>(Pf[i], Pg + i * NX);
                 }
             }
             if constexpr (FOLD) {
@@ -2132,7 +2144,7 @@ __global__ __launch_bounds__(64) void btd_direct_kernel(Buffers bf, int N, int B
 #pragma unroll
             for (int i = 0; i < CW; i++) {
                 const int c = c0 + i;
-                out[i] = (rowok && c < NX) ? base[(size_t)r * BR + off + c] : ((r == c) ? diag : 0.f);
+                out[i] = (rowok && c < NX) ? base[(size_t)off * NX + (size_t)r * NX + c] : ((r == c) ? diag : 0.f);   // off: 0 left block, NX main block
             }
         };
         float Di[CW];          // D_{k-1}^-1, this lane's entries
@@ -2155,7 +2167,7 @@ __global__ __launch_bounds__(64) void btd_direct_kernel(Buffers bf, int N, int B
                 load_slice(Sn, NX, Mn, 1.0f);
                 load_slice(Sn, 0, Ln, 0.f);
 #pragma unroll
-                for (int j = 0; j < NX; j++) Lrow[j] = rowok ? Sn[(size_t)r * BR + j] : 0.f;
+                for (int j = 0; j < NX; j++) Lrow[j] = rowok ? Sn[(size_t)r * NX + j] : 0.f;
                 gn = rowok ? gam[(k + 2) * NX + r] : 0.f;
             }
             if (k > 0) {
@@ -2202,7 +2214,7 @@ __global__ __launch_bounds__(64) void btd_direct_kernel(Buffers bf, int N, int B
             if (rowok) {
 #pragma unroll
                 for (int i = 0; i < CW; i++)
-                    if (c0 + i < NX) Dinv[(size_t)k * BROW + (size_t)r * BR + NX + c0 + i] = Di[i];
+                    if (c0 + i < NX) Dinv[(size_t)k * BROW + NX * NX + (size_t)r * NX + c0 + i] = Di[i];
                 if (cq == 0) lam[(k + 1) * NX + r] = g;   // g_k parks in lambda until the back substitution overwrites it
             }
         }
@@ -2218,7 +2230,7 @@ __global__ __launch_bounds__(64) void btd_direct_kernel(Buffers bf, int N, int B
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
                     const int i = cq + 4 * q;
-                    if (i < NX && rowok) acc = __builtin_fmaf(Ln1[(size_t)i * BR + r], sv[i], acc);
+                    if (i < NX && rowok) acc = __builtin_fmaf(Ln1[(size_t)i * NX + r], sv[i], acc);
                 }
                 rhs = rhs - quad_sum(acc);
             }

@@ -1000,6 +1000,19 @@ extern "C" int gato_debug_read(GatoSolver* s, const char* name, float* out, uint
     if (!out) return GATO_OK;
     if (count > l) return fail(GATO_ERR_INVALID, "count exceeds buffer length");
     HIPCHK(hipDeviceSynchronize());
+    if (!strcmp(name, "S") || !strcmp(name, "Pinv")) {
+        // the device keeps these block-major ([k][left | main | right][row][col]); the debug view is the reference's layout
+        // ([k][row][left | main | right], linalg.cuh:663-666), whole block rows only
+        const size_t nx = s->nx, blk = nx * nx, brow = 3 * blk;
+        if (count % brow) return fail(GATO_ERR_INVALID, "S / Pinv are read in whole block rows (3 nx^2 floats)");
+        std::vector<float> t(count);
+        HIPCHK(hipMemcpy(t.data(), p, count * sizeof(float), hipMemcpyDeviceToHost));
+        for (size_t r = 0; r < count / brow; r++)
+            for (size_t j = 0; j < 3; j++)
+                for (size_t y = 0; y < nx; y++)
+                    memcpy(out + r * brow + y * 3 * nx + j * nx, t.data() + r * brow + j * blk + y * nx, nx * sizeof(float));
+        return GATO_OK;
+    }
     HIPCHK(hipMemcpy(out, p, count * sizeof(float), hipMemcpyDeviceToHost));
     return GATO_OK;
 }
@@ -1019,6 +1032,17 @@ extern "C" int gato_debug_write(GatoSolver* s, const char* name, const float* in
         return fail(GATO_ERR_INVALID, std::string("unknown buffer ") + name);
     }
     if (count > l) return fail(GATO_ERR_INVALID, "count exceeds buffer length");
+    if (!strcmp(name, "S") || !strcmp(name, "Pinv")) {   // reference layout in, block-major on the device (see gato_debug_read)
+        const size_t nx = s->nx, blk = nx * nx, brow = 3 * blk;
+        if (count % brow) return fail(GATO_ERR_INVALID, "S / Pinv are written in whole block rows (3 nx^2 floats)");
+        std::vector<float> t(count);
+        for (size_t r = 0; r < count / brow; r++)
+            for (size_t j = 0; j < 3; j++)
+                for (size_t y = 0; y < nx; y++)
+                    memcpy(t.data() + r * brow + j * blk + y * nx, in + r * brow + y * 3 * nx + j * nx, nx * sizeof(float));
+        HIPCHK(hipMemcpy(p, t.data(), count * sizeof(float), hipMemcpyHostToDevice));
+        return GATO_OK;
+    }
     HIPCHK(hipMemcpy(p, in, count * sizeof(float), hipMemcpyHostToDevice));
     return GATO_OK;
 }

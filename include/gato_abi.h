@@ -144,7 +144,8 @@ int gato_ee_pos(GatoSolver* s, const float* q, int n, float* out);
 
 /* Debug / test access to a device buffer by name ("xu" = the solver's own copy used by gato_solve / gato_debug_stage):
  * "xu","D","Qq","Qd","Rd","q","r","c","Qqi","Qdi","Rdi","S","Pinv","gamma","lambda","dz","merit","merit_cur","rho","drho", "step".
- * Copies `count` floats to `out`; returns the buffer length in floats through *len when out == NULL. */
+ * Copies `count` floats to `out`; returns the buffer length in floats through *len when out == NULL.  "S" and "Pinv" are presented in
+ * the reference's layout [k][row][left | main | right] (linalg.cuh:663-666) whatever the device's internal one is. */
 int gato_debug_read(GatoSolver* s, const char* name, float* out, uint64_t count, uint64_t* len);
 int gato_debug_write(GatoSolver* s, const char* name, const float* in, uint64_t count);
 /* Runs ONE stage of an SQP iteration on device buffers previously filled (tests drive the stages one at a time):
