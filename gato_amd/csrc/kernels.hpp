@@ -1191,6 +1191,11 @@ __global__ __launch_bounds__(64) void schur2_kernel(Buffers bf, int N, int B, in
 // One workgroup per trajectory; thread t owns rows t, t + T (RPT <= 2) with their S / P^-1 rows in registers.
 // LDS: two padded vectors of (N+2) nx floats + reduction partials.
 // =========================================================================================================================
+// The two quotients of a PCG iteration (alpha = rho / pAp, beta = rho' / rho) as numerator x v_rcp_f32(denominator): 2 instructions
+// instead of the 12 of an IEEE division, on the per-wavefront instruction chain that bounds the launch.  v_rcp_f32 is good to 1 ulp;
+// the reference is built with -use_fast_math (CMakeLists.txt:22), whose division is the 2-ulp __fdividef.
+GATO_DEV float pcg_div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+
 template<int NXT> GATO_DEV float row_dot(const float* __restrict__ row, const float* __restrict__ win)
 {
     // win: LDS window of 3 nx floats starting at the left-neighbour block (16-byte aligned when nx % 4 == 0).
@@ -1376,7 +1381,7 @@ __global__ __launch_bounds__(MAXT) void pcg_kernel(Buffers bf, int N, int B, uin
                     loc += pv[u] * Ap[u];
                 }
                 const float pAp = block_sum(loc, partB);
-                const float alpha = rho / pAp;
+                const float alpha = pcg_div(rho, pAp);
 #pragma unroll
                 for (int u = 0; u < RPT; u++) {
                     xv[u] += alpha * pv[u];
@@ -1392,7 +1397,7 @@ __global__ __launch_bounds__(MAXT) void pcg_kernel(Buffers bf, int N, int B, uin
                 }
                 const float rho_new = block_sum(loc, partA);
                 if (fabsf(rho_new) < (abs_tol + eps * rho_init)) break;
-                const float beta = rho_new / rho;
+                const float beta = pcg_div(rho_new, rho);
                 rho = rho_new;
 #pragma unroll
                 for (int u = 0; u < RPT; u++) pv[u] = zv[u] + beta * pv[u];
@@ -1420,41 +1425,57 @@ __global__ __launch_bounds__(MAXT) void pcg_kernel(Buffers bf, int N, int B, uin
 // instruction; the matrix rows already sit in consecutive registers and the window arrives as 16-byte LDS reads, so no packing
 // moves are needed.  The pair is added once at the end.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+// Association of a row's 3 nx products (every register-resident PCG form shares it, so that they give the same bits): the row is cut
+// into two halves of 3 nx / 2 columns; each half accumulates its even and its odd columns in sequence (one packed FMA chain), and
+// the row sum is (even_lo + even_hi) + (odd_lo + odd_hi) -- the pair form of pcgc_kernel gives one half to each lane of a pair.
 template<int NXT, int RPT, bool PACKED = true> GATO_DEV void rows_dot(const float (*rows)[3 * NXT], const float* __restrict__ win, float* acc)
 {
+    constexpr int HP = (3 * NXT) / 4;   // float pairs per half (the halves split between pairs for every even nx)
+    static_assert((3 * NXT) % 4 == 0 || NXT % 4 != 0, "halves are whole pairs");
     if constexpr (!PACKED) {
-        // scalar form: two partial sums per row in the same (even, odd) order as the packed form, so both give the same bits
-        float e[RPT], o[RPT];
+        // scalar form of the same association
+        float e[2][RPT], o[2][RPT];
 #pragma unroll
-        for (int u = 0; u < RPT; u++) e[u] = o[u] = 0.f;
+        for (int u = 0; u < RPT; u++) e[0][u] = o[0][u] = e[1][u] = o[1][u] = 0.f;
 #pragma unroll
         for (int c = 0; c < 3 * NXT / 2; c++) {
             const float2 v = reinterpret_cast<const float2*>(win)[c];
+            const int hf = (NXT % 4 == 0 && c >= HP) ? 1 : 0;
 #pragma unroll
             for (int u = 0; u < RPT; u++) {
-                e[u] = __builtin_fmaf(rows[u][2 * c], v.x, e[u]);
-                o[u] = __builtin_fmaf(rows[u][2 * c + 1], v.y, o[u]);
+                e[hf][u] = __builtin_fmaf(rows[u][2 * c], v.x, e[hf][u]);
+                o[hf][u] = __builtin_fmaf(rows[u][2 * c + 1], v.y, o[hf][u]);
             }
         }
 #pragma unroll
-        for (int u = 0; u < RPT; u++) acc[u] = e[u] + o[u];
+        for (int u = 0; u < RPT; u++) acc[u] = (NXT % 4 == 0) ? (e[0][u] + e[1][u]) + (o[0][u] + o[1][u]) : e[0][u] + o[0][u];
         return;
     }
-    f32x2 a2[RPT];
-#pragma unroll
-    for (int u = 0; u < RPT; u++) a2[u] = f32x2{0.f, 0.f};
     if constexpr (NXT % 4 == 0) {
+        f32x2 a2[2][RPT];
+#pragma unroll
+        for (int u = 0; u < RPT; u++) a2[0][u] = a2[1][u] = f32x2{0.f, 0.f};
 #pragma unroll
         for (int c = 0; c < 3 * NXT / 4; c++) {
             const float4 v = reinterpret_cast<const float4*>(win)[c];
             const f32x2 lo = {v.x, v.y}, hi = {v.z, v.w};
 #pragma unroll
             for (int u = 0; u < RPT; u++) {
-                a2[u] = __builtin_elementwise_fma(f32x2{rows[u][4 * c], rows[u][4 * c + 1]}, lo, a2[u]);
-                a2[u] = __builtin_elementwise_fma(f32x2{rows[u][4 * c + 2], rows[u][4 * c + 3]}, hi, a2[u]);
+                f32x2& s0 = a2[(2 * c >= HP) ? 1 : 0][u];
+                s0 = __builtin_elementwise_fma(f32x2{rows[u][4 * c], rows[u][4 * c + 1]}, lo, s0);
+                f32x2& s1 = a2[(2 * c + 1 >= HP) ? 1 : 0][u];
+                s1 = __builtin_elementwise_fma(f32x2{rows[u][4 * c + 2], rows[u][4 * c + 3]}, hi, s1);
             }
         }
+#pragma unroll
+        for (int u = 0; u < RPT; u++) {
+            const f32x2 t = a2[0][u] + a2[1][u];   // one packed add: (even_lo + even_hi, odd_lo + odd_hi)
+            acc[u] = t.x + t.y;
+        }
     } else {
+        f32x2 a2[RPT];
+#pragma unroll
+        for (int u = 0; u < RPT; u++) a2[u] = f32x2{0.f, 0.f};
 #pragma unroll
         for (int c = 0; c < 3 * NXT / 2; c++) {
             const float2 v = reinterpret_cast<const float2*>(win)[c];
@@ -1462,9 +1483,9 @@ template<int NXT, int RPT, bool PACKED = true> GATO_DEV void rows_dot(const floa
 #pragma unroll
             for (int u = 0; u < RPT; u++) a2[u] = __builtin_elementwise_fma(f32x2{rows[u][2 * c], rows[u][2 * c + 1]}, w, a2[u]);
         }
-    }
 #pragma unroll
-    for (int u = 0; u < RPT; u++) acc[u] = a2[u].x + a2[u].y;
+        for (int u = 0; u < RPT; u++) acc[u] = a2[u].x + a2[u].y;
+    }
 }
 
 // Same dot products with the rows' RIGHT block (the last nx entries) parked in LDS as float4 [chunk][thread] (conflict-free): the
@@ -1474,17 +1495,20 @@ template<int NXT, int RPT> GATO_DEV void rows_dot_parked(const float (*rows)[3 *
 {
     static_assert(NXT % 4 == 0, "16-byte chunks");
     constexpr int CH = NXT / 4;  // chunks per block
-    f32x2 a2[RPT];
+    constexpr int HP = (3 * NXT) / 4;   // float pairs per half: rows_dot's association
+    f32x2 a2[2][RPT];
 #pragma unroll
-    for (int u = 0; u < RPT; u++) a2[u] = f32x2{0.f, 0.f};
+    for (int u = 0; u < RPT; u++) a2[0][u] = a2[1][u] = f32x2{0.f, 0.f};
 #pragma unroll
     for (int c = 0; c < 2 * CH; c++) {
         const float4 v = reinterpret_cast<const float4*>(win)[c];
         const f32x2 lo = {v.x, v.y}, hi = {v.z, v.w};
 #pragma unroll
         for (int u = 0; u < RPT; u++) {
-            a2[u] = __builtin_elementwise_fma(f32x2{rows[u][4 * c], rows[u][4 * c + 1]}, lo, a2[u]);
-            a2[u] = __builtin_elementwise_fma(f32x2{rows[u][4 * c + 2], rows[u][4 * c + 3]}, hi, a2[u]);
+            f32x2& s0 = a2[(2 * c >= HP) ? 1 : 0][u];
+            s0 = __builtin_elementwise_fma(f32x2{rows[u][4 * c], rows[u][4 * c + 1]}, lo, s0);
+            f32x2& s1 = a2[(2 * c + 1 >= HP) ? 1 : 0][u];
+            s1 = __builtin_elementwise_fma(f32x2{rows[u][4 * c + 2], rows[u][4 * c + 3]}, hi, s1);
         }
     }
 #pragma unroll
@@ -1494,12 +1518,15 @@ template<int NXT, int RPT> GATO_DEV void rows_dot_parked(const float (*rows)[3 *
 #pragma unroll
         for (int u = 0; u < RPT; u++) {
             const float4 m = park[(u * CH + c) * T];
-            a2[u] = __builtin_elementwise_fma(f32x2{m.x, m.y}, lo, a2[u]);
-            a2[u] = __builtin_elementwise_fma(f32x2{m.z, m.w}, hi, a2[u]);
+            a2[1][u] = __builtin_elementwise_fma(f32x2{m.x, m.y}, lo, a2[1][u]);   // the right block lies in the upper half (2 nx >= 3 nx / 2)
+            a2[1][u] = __builtin_elementwise_fma(f32x2{m.z, m.w}, hi, a2[1][u]);
         }
     }
 #pragma unroll
-    for (int u = 0; u < RPT; u++) acc[u] = a2[u].x + a2[u].y;
+    for (int u = 0; u < RPT; u++) {
+        const f32x2 t = a2[0][u] + a2[1][u];
+        acc[u] = t.x + t.y;
+    }
 }
 
 // FOLD: the stair off-diagonals of P^-1 (formSchurSystemBatchedKernel2, schur_linsys.cuh:213-260) are formed HERE, from the stored
@@ -1510,11 +1537,74 @@ template<int NXT, int RPT> GATO_DEV void rows_dot_parked(const float (*rows)[3 *
 // (schur_coop_rows / schur_coop_pinv: thread t of the PCG layout is lane t % 4 of the group of knot t / 4 - 1) instead of being
 // read back: S and P^-1 never exist in global memory, one launch and ~150 MB of traffic per iteration less.  Block row 0 (the
 // Q_0 rows) comes from the assembly kernel's cost task.
-template<class M, int RPT, int MAXT, bool FOLD, bool FUSE = false>
+// ---- helpers of the PAIR form of pcgc_kernel: a row group's 3 nx columns split over two lanes ----------------------------------
+// the partner lane's value: PM = 0 pairs are adjacent lanes (2g, 2g+1); PM = 1 pairs are lanes (t, t ^ 4) -- the two quads of an 8-lane
+// group (row_shl:4 into banks 0 and 2, row_shr:4 into banks 1 and 3)
+template<int PM> GATO_DEV float pair_partner(float p)
+{
+    if constexpr (PM == 0) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, p), 0xB1, 0xf, 0xf, false));
+    } else {
+        const int a = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, p), 0x104, 0xf, 0x5, false);
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(a, __builtin_bit_cast(int, p), 0x114, 0xf, 0xA, false));
+    }
+}
+template<int HC, int RPT, int PM = 0> GATO_DEV void rows_dot_half(const float (*rows)[HC], const float* w, float* acc)
+{
+    // w: the lane's half window in registers
+    static_assert(HC % 2 == 0, "whole pairs");
+    f32x2 a2[RPT];
+#pragma unroll
+    for (int u = 0; u < RPT; u++) a2[u] = f32x2{0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < HC / 2; c++) {
+        const f32x2 v = {w[2 * c], w[2 * c + 1]};
+#pragma unroll
+        for (int u = 0; u < RPT; u++) a2[u] = __builtin_elementwise_fma(f32x2{rows[u][2 * c], rows[u][2 * c + 1]}, v, a2[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < RPT; u++) {
+        const f32x2 t = a2[u] + f32x2{pair_partner<PM>(a2[u].x), pair_partner<PM>(a2[u].y)};   // rows_dot's association
+        acc[u] = t.x + t.y;
+    }
+}
+template<int HC> GATO_DEV void load_half_window(float* w, const float* __restrict__ win)   // 8-byte aligned LDS window
+{
+#pragma unroll
+    for (int c = 0; c < HC / 2; c++) {
+        const float2 v = reinterpret_cast<const float2*>(win)[c];
+        w[2 * c] = v.x;
+        w[2 * c + 1] = v.y;
+    }
+}
+// sum over the wavefront of a value that both lanes of every pair hold, each pair counted once: the butterfly step that would add
+// a lane to its partner is left out (PM = 0: quad_perm [1,0,3,2]; PM = 1: row_half_mirror, which adds the two quads of an 8-lane group)
+template<int PM = 0> GATO_DEV float wave_sum_pairs(float v)
+{
+#define GATO_DPP_ADD(ctrl) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, false))
+    if constexpr (PM == 1) GATO_DPP_ADD(0xB1);   // quad_perm [1,0,3,2]
+    GATO_DPP_ADD(0x4E);                           // quad_perm [2,3,0,1]
+    if constexpr (PM == 0) GATO_DPP_ADD(0x141);  // row_half_mirror
+    GATO_DPP_ADD(0x140);                          // row_mirror
+#undef GATO_DPP_ADD
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+    return (r3 + r2) + (r1 + r0);
+}
+GATO_DEV float read_parts(const float* part)   // <= 4 wavefront partials
+{
+    const float4 a = reinterpret_cast<const float4*>(part)[0];
+    return (a.x + a.y) + (a.z + a.w);
+}
+
+template<class M, int RPT, int MAXT, bool FOLD, bool FUSE = false, bool PAIR = false>
 __global__ __launch_bounds__(MAXT) void pcgc_kernel(Buffers bf, int N, int B, uint32_t max_iters, int sqp_iter, int write_p, float dt)
 {
     constexpr int NQ = M::NQ, NX = 2 * NQ, BR = 3 * NX, BROW = 3 * NX * NX;
     constexpr int PARTS = (FUSE || MAXT <= 256) ? 1 : (MAXT <= 512 ? 2 : 4);  // FUSE is only launched with <= 256 threads
+    static_assert(!PAIR || (FUSE && FOLD), "the pair form exists for the fused kernel");
     constexpr int LA2 = (NX % 4 == 0) ? 4 : 2;  // alignment (floats) of an nx-float row in the LDS buffers
     static_assert(NX % RPT == 0, "rows of one thread must share a block row");
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1532,8 +1622,11 @@ __global__ __launch_bounds__(MAXT) void pcgc_kernel(Buffers bf, int N, int B, ui
 
     if (!skip) {
         const float eps = bf.pcg_tol[b];
-        const int r0 = threadIdx.x * RPT;
-        const bool have = r0 < nrows;  // blockDim.x * RPT >= nrows; whole threads are in or out
+        // PAIR: lanes t and t ^ 4 (the two quads of an 8-lane group) run the SAME row group through the prologue (tid is the lane's
+        // index in the single-lane form) and then split its 3 nx columns for the iteration
+        const int tid = PAIR ? (int)(((threadIdx.x >> 3) << 2) | (threadIdx.x & 3)) : (int)threadIdx.x;
+        const int r0 = tid * RPT;
+        const bool have = r0 < nrows;  // threads * RPT >= nrows; whole threads are in or out
         const int rr = have ? r0 : 0;
         const int kb = rr / NX;
         const float* gam = bf.gamma + (size_t)b * vecp;
@@ -1693,7 +1786,7 @@ __global__ __launch_bounds__(MAXT) void pcgc_kernel(Buffers bf, int N, int B, ui
             }
         }
         // PARK: the right blocks of the P^-1 rows move to the LDS the fold no longer needs
-        constexpr bool PARK = FUSE && FOLD && (NX % 4 == 0);
+        constexpr bool PARK = FUSE && FOLD && (NX % 4 == 0) && !PAIR;
         const float4* park = nullptr;
         if constexpr (PARK) {
             float4* pk = reinterpret_cast<float4*>(partB + 16) + threadIdx.x;
@@ -1706,6 +1799,103 @@ __global__ __launch_bounds__(MAXT) void pcgc_kernel(Buffers bf, int N, int B, ui
                                                                       Prow[u][2 * NX + 4 * c + 3]);
             park = pk;
         }
+        if constexpr (PAIR) {
+            // The launch lasts as long as its slowest trajectory iterates (duration = a + 0.97 us x max iterations at C2, crowded or not,
+            // tools/exp_pcg_rate.py), and an iteration of the single-lane form is a dependent chain of 108 packed FMAs and 29 LDS reads
+            // issued in register-starved batches.  Here lane h of a pair keeps columns [HC h, HC h + HC) of [left | main | right] of
+            // its S and P^-1 rows: per product 27 packed FMAs behind 9 ds_read_b64 that are all in flight at once; two DPP moves
+            // fetch the partner's half sum, and the wavefront sum leaves out the butterfly that would add a lane to its partner.
+            constexpr int HC = BR / 2;
+            static_assert(BR % 4 == 0, "halves are whole float2 pairs");
+            const int h = (threadIdx.x >> 2) & 1;
+            const bool owner = have && h == 0;   // the lane of the pair that publishes the pair's vector entries
+            float Sh[RPT][HC], Ph[RPT][HC];
+#pragma unroll
+            for (int u = 0; u < RPT; u++)
+#pragma unroll
+                for (int c = 0; c < HC; c++) {
+                    Sh[u][c] = h ? Srow[u][HC + c] : Srow[u][c];
+                    Ph[u][c] = h ? Prow[u][HC + c] : Prow[u][c];
+                }
+            const float* wa = va + kb * NX + HC * h;
+            const float* wb = vb + kb * NX + HC * h;
+            float* oa = va + NX + rr;
+            float* ob = vb + NX + rr;
+            const bool lead = (threadIdx.x & 63) == 0;
+            const int wv = threadIdx.x >> 6;
+            for (int i = threadIdx.x; i < NX; i += blockDim.x) {
+                va[i] = 0.f; vb[i] = 0.f;
+                va[vecp - NX + i] = 0.f; vb[vecp - NX + i] = 0.f;
+            }
+            if (owner) store_vec<RPT, RPT>(oa, xv);
+            __syncthreads();
+            float w[HC], acc[RPT];
+            load_half_window<HC>(w, wa);
+            rows_dot_half<HC, RPT, 1>(Sh, w, acc);  // r = gamma - S x
+#pragma unroll
+            for (int u = 0; u < RPT; u++) rv[u] = have ? gv[u] - acc[u] : 0.f;
+            if (owner) store_vec<RPT, RPT>(ob, rv);
+            __syncthreads();
+            load_half_window<HC>(w, wb);
+            rows_dot_half<HC, RPT, 1>(Ph, w, acc);  // z = p = P^-1 r
+            float loc = 0.f;
+#pragma unroll
+            for (int u = 0; u < RPT; u++) {
+                zv[u] = have ? acc[u] : 0.f;
+                pv[u] = zv[u];
+                loc += rv[u] * zv[u];
+            }
+            loc = wave_sum_pairs<1>(loc);
+            if (lead) partA[wv] = loc;
+            __syncthreads();
+            float rho = read_parts(partA);
+            if (!(fabsf(rho) < abs_tol)) {
+                const float rho_init = fabsf(rho);
+                for (uint32_t it = 0; it < max_iters; it++) {
+                    iters++;
+                    if (owner) store_vec<RPT, RPT>(oa, pv);
+                    __syncthreads();
+                    load_half_window<HC>(w, wa);
+                    rows_dot_half<HC, RPT, 1>(Sh, w, acc);  // A p
+                    loc = 0.f;
+#pragma unroll
+                    for (int u = 0; u < RPT; u++) {
+                        if (!have) acc[u] = 0.f;
+                        loc += pv[u] * acc[u];
+                    }
+                    loc = wave_sum_pairs<1>(loc);
+                    if (lead) partB[wv] = loc;
+                    __syncthreads();
+                    const float pAp = read_parts(partB);
+                    const float alpha = pcg_div(rho, pAp);
+#pragma unroll
+                    for (int u = 0; u < RPT; u++) {
+                        xv[u] += alpha * pv[u];
+                        rv[u] -= alpha * acc[u];
+                    }
+                    if (owner) store_vec<RPT, RPT>(ob, rv);
+                    __syncthreads();
+                    load_half_window<HC>(w, wb);
+                    rows_dot_half<HC, RPT, 1>(Ph, w, acc);  // z = P^-1 r
+                    loc = 0.f;
+#pragma unroll
+                    for (int u = 0; u < RPT; u++) {
+                        zv[u] = have ? acc[u] : 0.f;
+                        loc += rv[u] * zv[u];
+                    }
+                    loc = wave_sum_pairs<1>(loc);
+                    if (lead) partA[wv] = loc;
+                    __syncthreads();
+                    const float rho_new = read_parts(partA);
+                    if (fabsf(rho_new) < (abs_tol + eps * rho_init)) break;
+                    const float beta = pcg_div(rho_new, rho);
+                    rho = rho_new;
+#pragma unroll
+                    for (int u = 0; u < RPT; u++) pv[u] = zv[u] + beta * pv[u];
+                }
+                if (owner) store_vec<RPT, RPT>(lam + NX + rr, xv);
+            }
+        } else {
         const float* wa = va + kb * NX;
         const float* wb = vb + kb * NX;
         float* oa = va + NX + rr;
@@ -1746,7 +1936,7 @@ __global__ __launch_bounds__(MAXT) void pcgc_kernel(Buffers bf, int N, int B, ui
                     loc += pv[u] * acc[u];
                 }
                 const float pAp = block_sum<PARTS>(loc, partB);
-                const float alpha = rho / pAp;
+                const float alpha = pcg_div(rho, pAp);
 #pragma unroll
                 for (int u = 0; u < RPT; u++) {
                     xv[u] += alpha * pv[u];
@@ -1764,12 +1954,13 @@ __global__ __launch_bounds__(MAXT) void pcgc_kernel(Buffers bf, int N, int B, ui
                 }
                 const float rho_new = block_sum<PARTS>(loc, partA);
                 if (fabsf(rho_new) < (abs_tol + eps * rho_init)) break;
-                const float beta = rho_new / rho;
+                const float beta = pcg_div(rho_new, rho);
                 rho = rho_new;
 #pragma unroll
                 for (int u = 0; u < RPT; u++) pv[u] = zv[u] + beta * pv[u];
             }
             if (have) store_vec<RPT, RPT>(lam + NX + rr, xv);
+        }
         }
     }
     if (threadIdx.x == 0) {
@@ -2045,7 +2236,7 @@ __global__ __launch_bounds__(MAXT, 2) void pcgs_kernel(Buffers bf, int N, int B,
                 if (mainrole) store_vec<HR, 1>(va + own, pv);
                 __syncthreads();
                 const float pAp = matvec(va, wina, no{}, acc, pv, partB);  // A p and p^T A p
-                const float alpha = rho / pAp;
+                const float alpha = pcg_div(rho, pAp);
 #pragma unroll
                 for (int i = 0; i < HR; i++) {
                     xv[i] += alpha * pv[i];
@@ -2055,7 +2246,7 @@ __global__ __launch_bounds__(MAXT, 2) void pcgs_kernel(Buffers bf, int N, int B,
                 __syncthreads();
                 const float rho_new = matvec(vb, winb, yes{}, zv, rv, partA);  // z = P^-1 r and r^T z
                 if (fabsf(rho_new) < (abs_tol + eps * rho_init)) break;
-                const float beta = rho_new / rho;
+                const float beta = pcg_div(rho_new, rho);
                 rho = rho_new;
 #pragma unroll
                 for (int i = 0; i < HR; i++) pv[i] = zv[i] + beta * pv[i];

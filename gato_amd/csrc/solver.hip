@@ -63,7 +63,7 @@ struct GatoSolver {
     // the PCG launch plan, decided ONCE when the solver is created (plan_pcg): which register-resident kernel runs (0 = the
     // streaming pcg_kernel), whether it forms the stair off-diagonals itself (then schur2_kernel is not launched) and whether the
     // Schur complement is formed inside it.  Tuning overrides GATO_PCG_VARIANT / GATO_PCG_FOLD are read there, never in the solve loop.
-    int pcg_choice, pcg_fold, pcg_fused;
+    int pcg_choice, pcg_fold, pcg_fused, pcg_pair;
     int linear_solver;  // 0: PCG (the reference's solver, pcg.cuh), 1: direct block-tridiagonal sweep (gato_set_linear_solver)
     // optional hipGraph replay of the host-buffer solve (gato_set_graph_mode): the fixed launch sequence of one solve captured once per
     // (dt, iteration count, mode switches) on the solver's own stream -- the buffers of gato_solve are the solver's own, so the kernel
@@ -391,6 +391,22 @@ template<class M> static int plan_pcg(GatoSolver* s)
         if (fused) fused = grant_lds(reinterpret_cast<const void*>(&pcgc_kernel<M, 3, 256, true, true>), pcg_fused_lds<M>(s));
     }
     s->pcg_fused = fused ? 1 : 0;
+    // Pair form of the fused kernel: two lanes per row group (twice the threads, half of the columns each; same bits).  A PCG iteration
+    // is a per-wavefront instruction chain, so halving a wavefront's share shortens it (0.79 vs 0.97 us per iteration) -- but the
+    // prologue still holds whole rows, the workgroup needs twice the registers, and only half as many trajectories fit a CU: it pays
+    // when ALL trajectories are resident at once (B <= 2 per CU at N = 32: -6 .. -13 % per solve for B <= 512, +7 % at B = 1024 where
+    // it would run in two rounds).  GATO_PCG_PAIR = 0 / 1 forces the choice.
+    bool pair = false;
+    if constexpr (NX == 12) {
+        const int T2 = 2 * PcgcShape<NX, 3, 0>::threads(s->N * s->nx);
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, s->device) != hipSuccess) cus = 0;
+        const char* pe = getenv("GATO_PCG_PAIR");
+        const bool want = pe ? atoi(pe) != 0 : (long)s->B * (T2 / 64) <= (long)cus * 8;   // 2 wavefronts per SIMD at 236 registers
+        pair = fused && want && T2 <= 256 && T2 >= 64 &&
+               grant_lds(reinterpret_cast<const void*>(&pcgc_kernel<M, 3, 256, true, true, true>), pcg_fused_lds<M>(s));
+    }
+    s->pcg_pair = pair ? 1 : 0;
     return GATO_OK;
 }
 static int plan_pcg_dispatch(GatoSolver* s) { return s->plant == GATO_PLANT_INDY7 ? plan_pcg<Indy7>(s) : plan_pcg<Iiwa14>(s); }
@@ -434,8 +450,12 @@ template<class M> static void launch_pcg_fused(GatoSolver* s, hipStream_t st, fl
     constexpr int NX = 2 * M::NQ;
     if constexpr (NX == 12) {
         const int T = PcgcShape<NX, 3, 0>::threads(s->N * s->nx);
-        hipLaunchKernelGGL((pcgc_kernel<M, 3, 256, true, true>), dim3(s->B), dim3(T), pcg_fused_lds<M>(s), st, s->bf, s->N, s->B,
-                           s->p.max_pcg_iters, sqp_iter, 0, dt);
+        if (s->pcg_pair)
+            hipLaunchKernelGGL((pcgc_kernel<M, 3, 256, true, true, true>), dim3(s->B), dim3(2 * T), pcg_fused_lds<M>(s), st, s->bf, s->N, s->B,
+                               s->p.max_pcg_iters, sqp_iter, 0, dt);
+        else
+            hipLaunchKernelGGL((pcgc_kernel<M, 3, 256, true, true>), dim3(s->B), dim3(T), pcg_fused_lds<M>(s), st, s->bf, s->N, s->B,
+                               s->p.max_pcg_iters, sqp_iter, 0, dt);
     }
 }
 

@@ -62,6 +62,7 @@ typedef struct {
     uint32_t iters_done, ls_done;
     int32_t* st_pcg_iters;  /* [max_sqp_iters][B] */
     float *st_min_merit, *st_step; /* [max_sqp_iters][B] */
+    float *st_merits, *st_merit_before; /* [max_sqp_iters][B][NUM_ALPHAS], [max_sqp_iters][B]: what every line search chose from (tests) */
     uint32_t* sqp_iters;    /* [B] */
     int32_t* kkt_converged; /* [B] */
     int nthreads;
@@ -941,6 +942,7 @@ Orc* orc_create(int plant, int N, int B, const OrcParams* p)
     size_t mi = p->max_sqp_iters ? p->max_sqp_iters : 1;
     o->st_pcg_iters = (int32_t*)calloc(mi * B, sizeof(int32_t));
     o->st_min_merit = ALLOCF(mi * B); o->st_step = ALLOCF(mi * B);
+    o->st_merits = ALLOCF(mi * B * NUM_ALPHAS); o->st_merit_before = ALLOCF(mi * B);
     o->sqp_iters = (uint32_t*)calloc(B, sizeof(uint32_t));
     o->kkt_converged = (int32_t*)calloc(B, sizeof(int32_t));
     return o;
@@ -950,7 +952,7 @@ void orc_destroy(Orc* o)
 {
     if (!o) return;
     float* fl[] = {o->lambda, o->rho, o->drho, o->rho_init, o->drho_init, o->mu, o->pcg_tol, o->f_ext, o->Q, o->R, o->q, o->r, o->A, o->Bm,
-                   o->c, o->Qinv, o->Rinv, o->S, o->Pinv, o->gamma, o->dz, o->merit, o->merit_cur, o->merit_init0, o->step, o->st_min_merit, o->st_step, o->pcg_work, o->costw};
+                   o->c, o->Qinv, o->Rinv, o->S, o->Pinv, o->gamma, o->dz, o->merit, o->merit_cur, o->merit_init0, o->step, o->st_min_merit, o->st_step, o->st_merits, o->st_merit_before, o->pcg_work, o->costw};
     for (size_t i = 0; i < sizeof(fl) / sizeof(fl[0]); i++) free(fl[i]);
     free(o->converged); free(o->pcg_iters); free(o->st_pcg_iters); free(o->sqp_iters); free(o->kkt_converged);
     free(o);
@@ -1040,6 +1042,8 @@ uint32_t orc_solve(Orc* o, float* xu, float dt, const float* x_s, const float* r
         if ((float)num_solved >= (float)B * o->p.solve_ratio) break; /* bsqp.cuh:165 */
         memcpy(o->converged, o->kkt_converged, B * sizeof(int32_t)); /* bsqp.cuh:167 */
         orc_merit(o, NUM_ALPHAS, o->merit, xu, x_s, ref, dt, 0);
+        memcpy(o->st_merits + (size_t)it * B * NUM_ALPHAS, o->merit, (size_t)B * NUM_ALPHAS * sizeof(float));
+        memcpy(o->st_merit_before + (size_t)it * B, o->merit_cur, B * sizeof(float));
         orc_line_search(o, xu);
         memcpy(o->st_min_merit + (size_t)it * B, o->merit_cur, B * sizeof(float));
         memcpy(o->st_step + (size_t)it * B, o->step, B * sizeof(float));
@@ -1068,7 +1072,7 @@ float* orc_buf(Orc* o, const char* name)
     M("Q", Q); M("R", R); M("q", q); M("r", r); M("A", A); M("B", Bm); M("c", c); M("Qinv", Qinv); M("Rinv", Rinv);
     M("S", S); M("Pinv", Pinv); M("gamma", gamma); M("lambda", lambda); M("dz", dz); M("merit", merit);
     M("merit_cur", merit_cur); M("merit_init0", merit_init0); M("step", step); M("rho", rho); M("drho", drho);
-    M("st_min_merit", st_min_merit); M("st_step", st_step);
+    M("st_min_merit", st_min_merit); M("st_step", st_step); M("st_merits", st_merits); M("st_merit_before", st_merit_before);
 #undef M
     return NULL;
 }

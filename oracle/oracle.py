@@ -221,6 +221,9 @@ class OracleSolver:
             "pcg_iters": self.ibuf("st_pcg_iters", (mi, B))[:ls],
             "ls_min_merit": np.ctypeslib.as_array(self.L.orc_buf(self.h, b"st_min_merit"), shape=(mi * B,)).reshape(mi, B)[:ls].copy(),
             "ls_step_size": np.ctypeslib.as_array(self.L.orc_buf(self.h, b"st_step"), shape=(mi * B,)).reshape(mi, B)[:ls].copy(),
+            # not part of the reference's dict: the candidates of every line search (8 merits + the merit before it), for the tests
+            "ls_merits": np.ctypeslib.as_array(self.L.orc_buf(self.h, b"st_merits"), shape=(mi * B * 8,)).reshape(mi, B, 8)[:ls].copy(),
+            "ls_merit_before": np.ctypeslib.as_array(self.L.orc_buf(self.h, b"st_merit_before"), shape=(mi * B,)).reshape(mi, B)[:ls].copy(),
             "iters_done": int(iters),
             "pcg_iters_all": self.ibuf("st_pcg_iters", (mi, B))[:iters],
         }

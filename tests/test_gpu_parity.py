@@ -188,22 +188,40 @@ def test_iterate_parity_tight_pcg(plant, N, B):
 def test_three_iterations_against_float64(plant, N, B):
     """Three free-running SQP iterations (rho adaptation on, lambda warm-started from iteration to iteration), PCG at its floor.
     The arbiter is the FLOAT64 build of the oracle: every trajectory of the HIP path must be as close to it as the fp32 oracle is
-    (no trajectory further away than 4 x the fp32 oracle's worst one; floor 2e-4 = the one-iteration fp32 gap), with the oracle's steps."""
+    (no trajectory further away than 4 x the fp32 oracle's worst one; floor 2e-4 = the one-iteration fp32 gap), with the float64 steps.
+    A trajectory may leave the float64 step sequence only through a NEAR TIE: at its first differing line search the float64 merits of
+    the two choices (8 candidates and "no step") differ by less than the fp32 error of a merit (1e-3 relative) -- a decision fp32
+    cannot make; such a trajectory (at most one in eight) is then only required to stay finite and to descend."""
     from oracle.oracle import OracleSolver
     nat, o32, pr = make(plant, N, B, 0.0, max_sqp_iters=3, **TIGHT)
     o64 = OracleSolver(plant, N, B, dt=DT, f64=True, **dict(DEFAULT_SOLVER_PARAMS, max_sqp_iters=3, **TIGHT))
     rg = nat.solve(pr["xu"], DT, pr["x_s"], pr["ref"])
     r32 = o32.solve(pr["xu"], DT, pr["x_s"], pr["ref"])
     r64 = o64.solve(pr["xu"], DT, pr["x_s"], pr["ref"])
-    clear = np.all(r32["ls_step_size"] == r64["ls_step_size"], axis=0)      # decisions that do not hinge on fp32 rounding
-    assert clear.all(), "the fp32 oracle and its float64 build disagree on a step: pick another seed for this test"
-    np.testing.assert_array_equal(rg["ls_step_size"], r32["ls_step_size"])
-    eg, eo = traj_err(rg["XU"], r64["XU"]), traj_err(r32["XU"], r64["XU"])
-    _report("free_3it", plant=plant, N=N, gpu_vs_f64=eg.max(), o32_vs_f64=eo.max(), gpu_vs_o32=traj_err(rg["XU"], r32["XU"]).max(),
-            worst_ratio=(eg / np.maximum(eo, 5e-5)).max())
+
+    def candidates(it, b):   # float64 merit of every choice of line search `it`: step 2^-i for i < 8, and no step (merit unchanged)
+        return {**{float(2.0 ** -i): float(r64["ls_merits"][it, b, i]) for i in range(8)}, 0.0: float(r64["ls_merit_before"][it, b])}
+
+    def follows(steps):      # per trajectory: the float64 steps, or a departure through a near tie
+        same = np.ones(B, bool)
+        for b in range(B):
+            d = np.nonzero(steps[:, b] != r64["ls_step_size"][:, b].astype(np.float32))[0]
+            if d.size:
+                same[b] = False
+                m = candidates(int(d[0]), b)
+                mine, ref = m.get(float(steps[d[0], b]), np.inf), m[float(r64["ls_step_size"][d[0], b])]
+                assert abs(mine - ref) <= 1e-3 * max(1.0, abs(ref)), "trajectory %d leaves the float64 steps at line search %d without a tie: %r" % (b, d[0], m)
+        return same
+    same_g, same_o = follows(rg["ls_step_size"]), follows(r32["ls_step_size"])
+    assert (~same_g).sum() <= max(1, B // 8), rg["ls_step_size"]
+    assert np.all(np.isfinite(rg["XU"])) and np.all(rg["final_merit"] <= rg["initial_merit"])
+    keep = same_g & same_o
+    eg, eo = traj_err(rg["XU"], r64["XU"])[keep], traj_err(r32["XU"], r64["XU"])[keep]
+    _report("free_3it", plant=plant, N=N, gpu_vs_f64=eg.max(), o32_vs_f64=eo.max(), gpu_vs_o32=traj_err(rg["XU"], r32["XU"])[keep].max(),
+            worst_ratio=(eg / np.maximum(eo, 5e-5)).max(), near_tie_departures=int((~same_g).sum()))
     assert np.all(eg <= max(2e-4, 4.0 * eo.max())), (eg, eo)   # no trajectory further from float64 than 4 x the worst fp32-oracle one
-    mg = np.abs(rg["final_merit"] - r64["final_merit"]) / np.maximum(1.0, np.abs(r64["final_merit"]))
-    mo = np.abs(r32["final_merit"] - r64["final_merit"]) / np.maximum(1.0, np.abs(r64["final_merit"]))
+    mg = (np.abs(rg["final_merit"] - r64["final_merit"]) / np.maximum(1.0, np.abs(r64["final_merit"])))[keep]
+    mo = (np.abs(r32["final_merit"] - r64["final_merit"]) / np.maximum(1.0, np.abs(r64["final_merit"])))[keep]
     assert np.all(mg <= max(2e-3, 4.0 * mo.max())), (mg, mo)
 
 
@@ -398,6 +416,26 @@ def test_fused_kernels_equal_separate_launches(N, B, fstd, monkeypatch):
     np.testing.assert_array_equal(f["ls_step_size"], g["ls_step_size"])
     np.testing.assert_array_equal(f["XU"], g["XU"])
     np.testing.assert_array_equal(f["final_merit"], g["final_merit"])
+
+
+@pytest.mark.parametrize("N,B,fstd", [(32, 24, 4.0), (16, 7, 2.0), (4, 3, 1.0), (8, 2, 0.0), (32, 600, 0.0)])
+def test_pair_form_of_the_pcg_kernel_equals_the_single_lane_form(N, B, fstd, monkeypatch):
+    """pcgc_kernel<.., PAIR> gives every row group to two lanes (half of the columns each; chosen when every trajectory of the batch is
+    resident in that form, B <= 512 at N = 32) -- the row sums associate as in the single-lane form and the wavefront sums run over the
+    same tree, so the batch size never changes a trajectory's bits: forced on and off, whole solves agree bit for bit."""
+    from gato_amd._lib import NativeSolver
+    p = dict(DEFAULT_SOLVER_PARAMS, max_sqp_iters=4)
+    pr = fig8_problem("indy7", N, B, f_ext_std=fstd)
+    out = {}
+    for v in ("0", "1"):
+        monkeypatch.setenv("GATO_PCG_PAIR", v)
+        s = NativeSolver("indy7", N, B, dt=DT, **p)   # read when the solver is created
+        s.set_f_ext_batch(pr["f_ext"])
+        out[v] = s.solve(pr["xu"], DT, pr["x_s"], pr["ref"])
+    monkeypatch.delenv("GATO_PCG_PAIR")
+    for k in ("pcg_iters_all", "ls_step_size", "XU", "final_merit"):
+        np.testing.assert_array_equal(out["0"][k], out["1"][k])
+    assert out["0"]["pcg_iters_all"].max() >= 5
 
 
 @pytest.mark.parametrize("plant,N,B,shard", [("iiwa14", 64, 4, 1), ("indy7", 32, 6, 5)])
@@ -624,10 +662,14 @@ def test_rho_reset_rule_without_adaptation():
         s.set_rho_penalty_batch(rho, True)
     rg = nat.solve(pr["xu"], DT, pr["x_s"], pr["ref"])
     ro = orc.solve(pr["xu"], DT, pr["x_s"], pr["ref"])
-    np.testing.assert_array_equal(rg["ls_step_size"], ro["ls_step_size"])
-    np.testing.assert_array_equal(nat.read("rho"), orc.buf("rho"))
-    failed = np.any(ro["ls_step_size"] < 0, axis=0)
-    assert np.all(orc.buf("rho")[failed & (rho > 10)] == np.float32(1e-3)) and np.all(orc.buf("rho")[~failed] == rho[~failed])
+    np.testing.assert_array_equal(rg["ls_step_size"][0], ro["ls_step_size"][0])   # first search: same inputs, same decisions
+    # with an absurd rho the step is useless and later searches are ties at rounding level: each side must apply the rule to ITS decisions
+    for steps, rho_after in ((rg["ls_step_size"], nat.read("rho")), (ro["ls_step_size"], orc.buf("rho"))):
+        failed = np.any(steps < 0, axis=0)
+        assert np.all(rho_after[failed & (rho > 10)] == np.float32(1e-3)) and np.all(rho_after[~(failed & (rho > 10))] == rho[~(failed & (rho > 10))])
+    same = np.all(rg["ls_step_size"] == ro["ls_step_size"], axis=0)
+    np.testing.assert_array_equal(nat.read("rho")[same], orc.buf("rho")[same])
+    assert np.any(np.any(ro["ls_step_size"] < 0, axis=0) & (rho > 10)), "the case must exercise the reset"
 
 
 @pytest.mark.parametrize("plant,N,B", [("indy7", 32, 6), ("iiwa14", 64, 3), ("iiwa14", 16, 5), ("indy7", 128, 2)])

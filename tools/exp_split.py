@@ -20,13 +20,29 @@ print("total pcg iters: max %d mean %.1f; sum of per-launch max %d" % (tot.max()
 
 def dev_t(a): return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 
-def timed(groups, prio, reps=20):
+import ctypes
+_hip = ctypes.CDLL("libamdhip64.so")
+
+
+def masked_stream(cu_lo, cu_hi, total=256):
+    """a stream whose kernels only run on CUs [cu_lo, cu_hi) (hipExtStreamCreateWithCUMask)"""
+    words = (total + 31) // 32
+    m = (ctypes.c_uint32 * words)()
+    for c in range(cu_lo, cu_hi):
+        m[c // 32] |= 1 << (c % 32)
+    st = ctypes.c_void_p()
+    rc = _hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), ctypes.c_uint32(words), m)
+    assert rc == 0, rc
+    return torch.cuda.ExternalStream(st.value)
+
+
+def timed(groups, prio, reps=20, masks=None):
     hs, bufs, streams = [], [], []
     for gi, idx in enumerate(groups):
         s = NativeSolver("indy7", N, len(idx), dt=0.01, **p)
         hs.append(s)
         bufs.append((dev_t(pr["xu"][idx]), torch.empty((len(idx), full.traj), device=dev), dev_t(pr["x_s"][idx]), dev_t(pr["ref"][idx])))
-        streams.append(torch.cuda.Stream(priority=prio[gi]))
+        streams.append(masked_stream(*masks[gi]) if masks else torch.cuda.Stream(priority=prio[gi]))
     def step():
         for s, (x0, x, xs, ref), st in zip(hs, bufs, streams):
             with torch.cuda.stream(st):
@@ -50,3 +66,23 @@ for H in (16, 32, 64, 128, 256, 512):
         t, xo = timed([easy, hard], prio)
         ok = np.array_equal(xo[0], x_full[0][easy]) and np.array_equal(xo[1], x_full[0][hard])
         print("H=%4d prio %s: %.1f us per solve (%.2fx)  bit-equal to the single batch: %s" % (H, prio, t * 1e6, t_full / t, ok))
+
+print("CU-masked streams (hipExtStreamCreateWithCUMask): hard sub-batch on its own CUs")
+t_m, _ = timed([np.arange(B)], [0], masks=[(0, 256)])
+print("single batch on a stream masked to all 256 CUs: %.1f us" % (t_m * 1e6))
+for stride in (False, True):
+  for H, C in ((32, 32), (64, 32), (64, 64), (128, 64), (128, 32), (256, 64), (256, 128)):
+    hard, easy = np.sort(order[:H]), np.sort(order[H:])
+    t, xo = timed([easy, hard], (0, 0), masks=[(C, 256), (0, C)])
+    ok = np.array_equal(xo[0], x_full[0][easy]) and np.array_equal(xo[1], x_full[0][hard])
+    print("H=%4d on %3d CUs, rest on %3d: %.1f us per solve (%.2fx)  bit-equal: %s" % (H, C, 256 - C, t * 1e6, t_full / t, ok), flush=True)
+  break
+# the hard sub-batch alone on its CU partition: its own chain
+for H, C in ((32, 32), (64, 32), (64, 64), (128, 64)):
+    hard = np.sort(order[:H])
+    t, _ = timed([hard], (0,), masks=[(0, C)])
+    print("hard %d alone on %d CUs: %.1f us" % (H, C, t * 1e6), flush=True)
+for H, C in ((32, 32), (64, 32), (64, 64), (128, 64)):
+    easy = np.sort(order[H:])
+    t, _ = timed([easy], (0,), masks=[(C, 256)])
+    print("easy %d alone on %d CUs: %.1f us" % (B - H, 256 - C, t * 1e6), flush=True)
