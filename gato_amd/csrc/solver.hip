@@ -366,7 +366,9 @@ template<class M> static int plan_pcg(GatoSolver* s)
     else if ((v == 100 || v == 3) && pcgc_fits<M, 2>(s)) choice = 3;
     else if ((v == 100 || v == 1) && pcgc_fits<M, 6>(s)) choice = 1;
     // symmetric half storage: asked for (7), or the default where no full-storage kernel holds the system (iiwa14 N = 128)
-    if ((v == 7 || (v == 100 && choice == 0)) && s->N >= 16 && 4 * s->N <= 512 && pcgs_grant<M>(s)) choice = 7;
+    // ... and ahead of the 6-rows-per-thread form, whose 432 matrix registers per lane live in AGPRs (indy7 N = 128: 296 vs 341 us per
+    // one-iteration solve at B = 1, 1.49 vs 1.96 ms at B = 1024)
+    if ((v == 7 || (v == 100 && (choice == 0 || choice == 1))) && s->N >= 16 && 4 * s->N <= 512 && pcgs_grant<M>(s)) choice = 7;
     s->pcg_choice = choice;
     // the kernel that will run forms the stair off-diagonals itself when the two fold buffers + the vectors fit one CU's LDS and the
     // runtime grants them; otherwise schur2_kernel is launched (launch_schur) and the kernel reads the complete P^-1
