@@ -7,6 +7,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "csrc", "libgato_hip.so")
+LIB_PATH_F64 = os.path.join(HERE, "csrc", "libgato_hip_f64.so")   # the USE_DOUBLES build (gato/settings.h:7-11): same entry points on double
 PLANTS = {"indy7": 0, "iiwa14": 1}
 NQ = {"indy7": 6, "iiwa14": 7}
 
@@ -22,11 +23,15 @@ SYMBOLS = [
 ]
 
 
-class GatoParams(C.Structure):
-    _fields_ = [("dt", C.c_float), ("max_sqp_iters", C.c_uint32), ("kkt_tol", C.c_float), ("max_pcg_iters", C.c_uint32),
-                ("pcg_tol", C.c_float), ("solve_ratio", C.c_float), ("mu", C.c_float), ("q_cost", C.c_float), ("qd_cost", C.c_float),
-                ("u_cost", C.c_float), ("N_cost", C.c_float), ("q_lim_cost", C.c_float), ("vel_lim_cost", C.c_float),
-                ("ctrl_lim_cost", C.c_float), ("rho", C.c_float)]
+def _params_struct(ft, name):
+    return type(name, (C.Structure,), {"_fields_": [
+        ("dt", ft), ("max_sqp_iters", C.c_uint32), ("kkt_tol", ft), ("max_pcg_iters", C.c_uint32), ("pcg_tol", ft), ("solve_ratio", ft),
+        ("mu", ft), ("q_cost", ft), ("qd_cost", ft), ("u_cost", ft), ("N_cost", ft), ("q_lim_cost", ft), ("vel_lim_cost", ft),
+        ("ctrl_lim_cost", ft), ("rho", ft)]})
+
+
+GatoParams = _params_struct(C.c_float, "GatoParams")
+GatoParamsF64 = _params_struct(C.c_double, "GatoParamsF64")
 
 
 class GatoError(RuntimeError):
@@ -34,6 +39,7 @@ class GatoError(RuntimeError):
 
 
 _lib = None
+_libs = {}
 
 
 def preload_torch():
@@ -46,25 +52,30 @@ def preload_torch():
             pass
 
 
-def load():
-    """Loads libgato_hip.so for the ctypes binding (the tests' back door to the stage / debug entry points; the product's Python
-    classes are the compiled ones of gato_amd._gato_ext)."""
+def load(f64=False):
+    """Loads libgato_hip.so (or its float64 build) for the ctypes binding (the tests' back door to the stage / debug entry points; the
+    product's Python classes are the compiled ones of gato_amd._gato_ext)."""
     global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
-        raise GatoError("libgato_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C gato_amd/csrc`."
-                        % LIB_PATH)
+    f64 = bool(f64)
+    if f64 in _libs:
+        return _libs[f64]
+    path = LIB_PATH_F64 if f64 else LIB_PATH
+    if not os.path.exists(path):
+        raise GatoError("%s is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C gato_amd/csrc`."
+                        % (os.path.basename(path), path))
     preload_torch()
-    L = C.CDLL(LIB_PATH)
-    fp, ip, vp = C.POINTER(C.c_float), C.POINTER(C.c_int32), C.c_void_p
-    L.gato_default_params.argtypes = [C.POINTER(GatoParams)]
+    L = C.CDLL(path)
+    ft = C.c_double if f64 else C.c_float
+    PT = GatoParamsF64 if f64 else GatoParams
+    L._ft, L._np, L._PT = ft, (np.float64 if f64 else np.float32), PT
+    fp, ip, vp = C.POINTER(ft), C.POINTER(C.c_int32), C.c_void_p
+    L.gato_default_params.argtypes = [C.POINTER(PT)]
     L.gato_default_params.restype = None
     L.gato_dims.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
-    L.gato_create.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(GatoParams), C.POINTER(vp)]
+    L.gato_create.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(PT), C.POINTER(vp)]
     L.gato_destroy.argtypes = [vp]
-    L.gato_solve.argtypes = [vp, fp, C.c_float, fp, fp, C.POINTER(C.c_double)]
-    L.gato_solve_device.argtypes = [vp, vp, C.c_float, vp, vp, vp]
+    L.gato_solve.argtypes = [vp, fp, ft, fp, fp, C.POINTER(C.c_double)]
+    L.gato_solve_device.argtypes = [vp, vp, ft, vp, vp, vp]
     L.gato_get_counts.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     for n in ("gato_get_sqp_iters", "gato_get_kkt_converged", "gato_get_pcg_iters"):
         getattr(L, n).argtypes = [vp, ip]
@@ -78,30 +89,32 @@ def load():
     L.gato_set_rho_adaptation.argtypes = [vp, C.c_int]
     L.gato_set_linear_solver.argtypes = [vp, C.c_int]
     L.gato_set_graph_mode.argtypes = [vp, C.c_int]
-    L.gato_sim_forward.argtypes = [vp, fp, fp, fp, C.c_float]
+    L.gato_sim_forward.argtypes = [vp, fp, fp, fp, ft]
     L.gato_ee_pos.argtypes = [vp, fp, C.c_int, fp]
     L.gato_debug_read.argtypes = [vp, C.c_char_p, fp, C.c_uint64, C.POINTER(C.c_uint64)]
     L.gato_debug_write.argtypes = [vp, C.c_char_p, fp, C.c_uint64]
-    L.gato_debug_stage.argtypes = [vp, C.c_int, fp, C.c_float, fp, fp, fp]
+    L.gato_debug_stage.argtypes = [vp, C.c_int, fp, ft, fp, fp, fp]
     L.gato_set_profiling.argtypes = [vp, C.c_int]
     L.gato_get_stage_times_us.argtypes = [vp, C.POINTER(C.c_double)]
     L.gato_reset_async.argtypes = [vp, C.c_int, C.c_int, vp]
     L.gato_copy_final_merit_device.argtypes = [vp, vp, vp]
     L.gato_synchronize.argtypes = [vp]
-    L.gato_plant_rk4.argtypes = [vp, fp, fp, C.c_int, fp, C.c_float]
+    L.gato_plant_rk4.argtypes = [vp, fp, fp, C.c_int, fp, ft]
     L.gato_fk_placements.argtypes = [C.c_int, fp, C.POINTER(C.c_double)]
-    L.gato_select_best.argtypes = [vp, fp, fp, fp, C.c_float, C.POINTER(C.c_int), fp]
-    L.gato_select_best_device.argtypes = [vp, vp, vp, vp, C.c_float, vp, vp, vp]
-    L.gato_sim_forward_device.argtypes = [vp, vp, vp, vp, C.c_float, vp]
+    L.gato_select_best.argtypes = [vp, fp, fp, fp, ft, C.POINTER(C.c_int), fp]
+    L.gato_select_best_device.argtypes = [vp, vp, vp, vp, ft, vp, vp, vp]
+    L.gato_sim_forward_device.argtypes = [vp, vp, vp, vp, ft, vp]
     L.gato_last_error.restype = C.c_char_p
     L.gato_version.restype = C.c_char_p
-    _lib = L
+    _libs[f64] = L
+    if not f64:
+        _lib = L
     return L
 
 
-def _chk(rc):
+def _chk(rc, L=None):
     if rc != 0:
-        raise GatoError("libgato_hip: status %d: %s" % (rc, load().gato_last_error().decode()))
+        raise GatoError("libgato_hip: status %d: %s" % (rc, (L or load()).gato_last_error().decode()))
 
 
 def _f32(a, shape=None):
@@ -130,15 +143,17 @@ STAGES = {"merit8": 0, "kkt": 1, "schur": 2, "pcg": 3, "dz": 4, "line_search": 5
 class NativeSolver:
     """Owns one `GatoSolver*`.  Method names follow PyBSQP<T,B> (python/bindings.cu:224-237)."""
 
-    def __init__(self, plant, knot_points, batch_size, **params):
-        L = load()
+    def __init__(self, plant, knot_points, batch_size, f64=False, **params):
+        """f64: the USE_DOUBLES build (libgato_hip_f64.so, validation mode: stand-alone kernels, double buffers)"""
+        L = self.L = load(f64)
+        self.dtype, self._ft = L._np, L._ft
         if plant not in PLANTS:
             raise ValueError("unknown plant %r" % (plant,))
         self.plant, self.N, self.B = plant, int(knot_points), int(batch_size)
         self.nq = NQ[plant]
         self.nx, self.nu = 2 * self.nq, self.nq
         self.traj = (self.nx + self.nu) * self.N - self.nu
-        p = GatoParams()
+        p = L._PT()
         L.gato_default_params(C.byref(p))
         for k, v in params.items():
             if k not in PARAM_ORDER:
@@ -146,12 +161,22 @@ class NativeSolver:
             setattr(p, k, v)
         self.params = p
         h = C.c_void_p()
-        _chk(L.gato_create(PLANTS[plant], self.N, self.B, C.byref(p), C.byref(h)))
+        self._chk(L.gato_create(PLANTS[plant], self.N, self.B, C.byref(p), C.byref(h)))
         self.h = h
+
+    def _chk(self, rc):
+        _chk(rc, self.L)
+
+    def _f(self, a, shape=None):
+        a = np.ascontiguousarray(a, dtype=self.dtype)
+        return a if shape is None else a.reshape(shape)
+
+    def _p(self, a):
+        return a.ctypes.data_as(C.POINTER(self._ft))
 
     def close(self):
         if getattr(self, "h", None):
-            load().gato_destroy(self.h)
+            self.L.gato_destroy(self.h)
             self.h = None
 
     def __del__(self):
@@ -164,12 +189,12 @@ class NativeSolver:
     def solve(self, xu, timestep, x_s, ref):
         """PyBSQP::solve (bindings.cu:68-148): returns the same dict (XU, sqp_time_us, sqp_iters, kkt_converged, final_merit,
         initial_merit, ls_num_iters, pcg_times_us, pcg_iters, ls_min_merit, ls_step_size)."""
-        L = load()
-        xu = np.array(xu, dtype=np.float32, order="C").reshape(self.B, self.traj)
-        x_s = _f32(x_s, (self.B, self.nx))
-        ref = _f32(ref, (self.B, 6 * self.N))
+        L = self.L
+        xu = np.array(xu, dtype=self.dtype, order="C").reshape(self.B, self.traj)
+        x_s = self._f(x_s, (self.B, self.nx))
+        ref = self._f(ref, (self.B, 6 * self.N))
         t = C.c_double(0.0)
-        _chk(L.gato_solve(self.h, _p(xu), float(timestep), _p(x_s), _p(ref), C.byref(t)))
+        self._chk(L.gato_solve(self.h, self._p(xu), float(timestep), self._p(x_s), self._p(ref), C.byref(t)))
         out = self.stats()
         out["XU"] = xu
         out["sqp_time_us"] = t.value
@@ -177,38 +202,38 @@ class NativeSolver:
 
     def solve_device(self, d_xu, timestep, d_x_s, d_ref, stream=0):
         """BSQP::solve on raw device pointers (ints), asynchronous on `stream`."""
-        _chk(load().gato_solve_device(self.h, C.c_void_p(d_xu), float(timestep), C.c_void_p(d_x_s), C.c_void_p(d_ref), C.c_void_p(stream)))
+        self._chk(self.L.gato_solve_device(self.h, C.c_void_p(d_xu), float(timestep), C.c_void_p(d_x_s), C.c_void_p(d_ref), C.c_void_p(stream)))
 
     def reset_async(self, dual=True, rho=True, stream=0):
-        _chk(load().gato_reset_async(self.h, int(dual), int(rho), C.c_void_p(stream)))
+        self._chk(self.L.gato_reset_async(self.h, int(dual), int(rho), C.c_void_p(stream)))
 
     def copy_final_merit_device(self, d_out, stream=0):
-        _chk(load().gato_copy_final_merit_device(self.h, C.c_void_p(d_out), C.c_void_p(stream)))
+        self._chk(self.L.gato_copy_final_merit_device(self.h, C.c_void_p(d_out), C.c_void_p(stream)))
 
     def stats(self):
-        L = load()
+        L = self.L
         B = self.B
         it, ls = C.c_uint32(0), C.c_uint32(0)
-        _chk(L.gato_get_counts(self.h, C.byref(it), C.byref(ls)))
+        self._chk(L.gato_get_counts(self.h, C.byref(it), C.byref(ls)))
         it, ls = it.value, ls.value
         sqp_iters = np.zeros(B, np.int32)
         conv = np.zeros(B, np.int32)
-        fm = np.zeros(B, np.float32)
-        im = np.zeros(B, np.float32)
+        fm = np.zeros(B, self.dtype)
+        im = np.zeros(B, self.dtype)
         pcg = np.zeros((max(it, 1), B), np.int32)
-        mm = np.zeros((max(ls, 1), B), np.float32)
-        ss = np.zeros((max(ls, 1), B), np.float32)
+        mm = np.zeros((max(ls, 1), B), self.dtype)
+        ss = np.zeros((max(ls, 1), B), self.dtype)
         ip = C.POINTER(C.c_int32)
-        _chk(L.gato_get_sqp_iters(self.h, sqp_iters.ctypes.data_as(ip)))
-        _chk(L.gato_get_kkt_converged(self.h, conv.ctypes.data_as(ip)))
-        _chk(L.gato_get_final_merit(self.h, _p(fm)))
-        _chk(L.gato_get_initial_merit(self.h, _p(im)))
-        _chk(L.gato_get_pcg_iters(self.h, pcg.ctypes.data_as(ip)))
-        _chk(L.gato_get_ls_min_merit(self.h, _p(mm)))
-        _chk(L.gato_get_ls_step_size(self.h, _p(ss)))
+        self._chk(L.gato_get_sqp_iters(self.h, sqp_iters.ctypes.data_as(ip)))
+        self._chk(L.gato_get_kkt_converged(self.h, conv.ctypes.data_as(ip)))
+        self._chk(L.gato_get_final_merit(self.h, self._p(fm)))
+        self._chk(L.gato_get_initial_merit(self.h, self._p(im)))
+        self._chk(L.gato_get_pcg_iters(self.h, pcg.ctypes.data_as(ip)))
+        self._chk(L.gato_get_ls_min_merit(self.h, self._p(mm)))
+        self._chk(L.gato_get_ls_step_size(self.h, self._p(ss)))
         return {
             "sqp_iters": sqp_iters, "kkt_converged": conv, "final_merit": fm, "initial_merit": im, "ls_num_iters": int(ls),
-            "pcg_times_us": np.zeros(ls, np.float32),       # always 0 in the reference too (bsqp.cuh:138)
+            "pcg_times_us": np.zeros(ls, self.dtype),       # always 0 in the reference too (bsqp.cuh:138)
             "pcg_iters": pcg[:ls],                            # the reference truncates to the line searches done (bindings.cu:111-128)
             "ls_min_merit": mm[:ls], "ls_step_size": ss[:ls],
             "iters_done": int(it), "pcg_iters_all": pcg[:it],
@@ -216,110 +241,110 @@ class NativeSolver:
 
     # ---- setters ----
     def set_f_ext_batch(self, f):
-        _chk(load().gato_set_f_ext_batch(self.h, _p(_f32(f, (self.B, 6)))))
+        self._chk(self.L.gato_set_f_ext_batch(self.h, self._p(self._f(f, (self.B, 6)))))
 
     def set_rho_penalty_batch(self, v, set_as_reset_default=True):
-        _chk(load().gato_set_rho_penalty_batch(self.h, _p(_f32(v, (self.B,))), int(bool(set_as_reset_default))))
+        self._chk(self.L.gato_set_rho_penalty_batch(self.h, self._p(self._f(v, (self.B,))), int(bool(set_as_reset_default))))
 
     def set_drho_batch(self, v, set_as_reset_default=True):
-        _chk(load().gato_set_drho_batch(self.h, _p(_f32(v, (self.B,))), int(bool(set_as_reset_default))))
+        self._chk(self.L.gato_set_drho_batch(self.h, self._p(self._f(v, (self.B,))), int(bool(set_as_reset_default))))
 
     def set_mu_batch(self, v):
-        _chk(load().gato_set_mu_batch(self.h, _p(_f32(v, (self.B,)))))
+        self._chk(self.L.gato_set_mu_batch(self.h, self._p(self._f(v, (self.B,)))))
 
     def set_cost_weights_batch(self, w):
         """w[B,7] = q, qd, u, N, q_lim, vel_lim, ctrl_lim cost weights per trajectory (extension: SURVEY 8(f)3)"""
-        _chk(load().gato_set_cost_weights_batch(self.h, _p(_f32(w, (self.B, 7)))))
+        self._chk(self.L.gato_set_cost_weights_batch(self.h, self._p(self._f(w, (self.B, 7)))))
 
     def set_pcg_tol_batch(self, v):
-        _chk(load().gato_set_pcg_tol_batch(self.h, _p(_f32(v, (self.B,)))))
+        self._chk(self.L.gato_set_pcg_tol_batch(self.h, self._p(self._f(v, (self.B,)))))
 
     def reset_dual(self):
-        _chk(load().gato_reset_dual(self.h))
+        self._chk(self.L.gato_reset_dual(self.h))
 
     def reset_rho(self):
-        _chk(load().gato_reset_rho(self.h))
+        self._chk(self.L.gato_reset_rho(self.h))
 
     def set_rho_adaptation(self, enabled):
-        _chk(load().gato_set_rho_adaptation(self.h, int(bool(enabled))))
+        self._chk(self.L.gato_set_rho_adaptation(self.h, int(bool(enabled))))
 
     def set_graph_mode(self, enabled):
         """replay the host-buffer solve as a hipGraph (bit-identical; off by default)"""
-        _chk(load().gato_set_graph_mode(self.h, int(bool(enabled))))
+        self._chk(self.L.gato_set_graph_mode(self.h, int(bool(enabled))))
 
     def set_linear_solver(self, mode):
         """"pcg" (the reference's solver) or "direct" (block-tridiagonal LU sweep; extension)"""
-        _chk(load().gato_set_linear_solver(self.h, {"pcg": 0, "direct": 1}[mode]))
+        self._chk(self.L.gato_set_linear_solver(self.h, {"pcg": 0, "direct": 1}[mode]))
 
     def sim_forward(self, xk, uk, dt):
-        out = np.zeros((self.B, self.nx), np.float32)
-        _chk(load().gato_sim_forward(self.h, _p(out), _p(_f32(xk, (self.nx,))), _p(_f32(uk, (self.nu,))), float(dt)))
+        out = np.zeros((self.B, self.nx), self.dtype)
+        self._chk(self.L.gato_sim_forward(self.h, self._p(out), self._p(self._f(xk, (self.nx,))), self._p(self._f(uk, (self.nu,))), float(dt)))
         return out
 
     def sim_forward_device(self, d_xkp1, d_xk, d_uk, dt, stream=0):
         """BSQP::sim_forward on raw device pointers (ints), asynchronous on `stream` (bsqp.cuh:91)."""
-        _chk(load().gato_sim_forward_device(self.h, C.c_void_p(d_xkp1), C.c_void_p(d_xk), C.c_void_p(d_uk), float(dt), C.c_void_p(stream)))
+        self._chk(self.L.gato_sim_forward_device(self.h, C.c_void_p(d_xkp1), C.c_void_p(d_xk), C.c_void_p(d_uk), float(dt), C.c_void_p(stream)))
 
     def select_best(self, x_last, u_last, x_meas, dt):
         """(best index, errors[B]): MPC hypothesis selection on the device (mpc_controller.py:294-309)"""
-        err = np.zeros(self.B, np.float32)
+        err = np.zeros(self.B, self.dtype)
         best = C.c_int(0)
-        _chk(load().gato_select_best(self.h, _p(_f32(x_last, (self.nx,))), _p(_f32(u_last, (self.nu,))), _p(_f32(x_meas, (self.nx,))), float(dt),
-                                     C.byref(best), _p(err)))
+        self._chk(self.L.gato_select_best(self.h, self._p(self._f(x_last, (self.nx,))), self._p(self._f(u_last, (self.nu,))), self._p(self._f(x_meas, (self.nx,))), float(dt),
+                                     C.byref(best), self._p(err)))
         return best.value, err
 
     def plant_rk4(self, x, u_seq, f_ext6, sim_dt):
         """nsteps = len(u_seq) RK4 steps of the library's forward dynamics (the MPC loop's plant simulator); returns the new state"""
-        x = np.array(x, dtype=np.float32).reshape(self.nx)
-        u = _f32(u_seq).reshape(-1, self.nu)
-        _chk(load().gato_plant_rk4(self.h, _p(x), _p(u), int(u.shape[0]), _p(_f32(f_ext6, (6,))), float(sim_dt)))
+        x = np.array(x, dtype=self.dtype).reshape(self.nx)
+        u = self._f(u_seq).reshape(-1, self.nu)
+        self._chk(self.L.gato_plant_rk4(self.h, self._p(x), self._p(u), int(u.shape[0]), self._p(self._f(f_ext6, (6,))), float(sim_dt)))
         return x
 
     def synchronize(self):
-        _chk(load().gato_synchronize(self.h))
+        self._chk(self.L.gato_synchronize(self.h))
 
     def ee_pos(self, q):
-        q = _f32(q).reshape(-1, self.nq)
-        out = np.zeros((q.shape[0], 3), np.float32)
-        _chk(load().gato_ee_pos(self.h, _p(q), q.shape[0], _p(out)))
+        q = self._f(q).reshape(-1, self.nq)
+        out = np.zeros((q.shape[0], 3), self.dtype)
+        self._chk(self.L.gato_ee_pos(self.h, self._p(q), q.shape[0], self._p(out)))
         return out
 
     # ---- profiling / debug ----
     def set_profiling(self, enabled):
-        _chk(load().gato_set_profiling(self.h, int(bool(enabled))))
+        self._chk(self.L.gato_set_profiling(self.h, int(bool(enabled))))
 
     def stage_times_us(self):
         out = (C.c_double * 7)()
-        _chk(load().gato_get_stage_times_us(self.h, out))
+        self._chk(self.L.gato_get_stage_times_us(self.h, out))
         return dict(zip(["merit", "kkt", "schur", "pcg", "dz", "line_search", "total"], list(out)))
 
     def read(self, name):
         n = C.c_uint64(0)
-        _chk(load().gato_debug_read(self.h, name.encode(), None, 0, C.byref(n)))
-        out = np.zeros(n.value, np.float32)
-        _chk(load().gato_debug_read(self.h, name.encode(), _p(out), n.value, None))
+        self._chk(self.L.gato_debug_read(self.h, name.encode(), None, 0, C.byref(n)))
+        out = np.zeros(n.value, self.dtype)
+        self._chk(self.L.gato_debug_read(self.h, name.encode(), self._p(out), n.value, None))
         return out
 
     def write(self, name, arr):
-        a = _f32(arr).reshape(-1)
-        _chk(load().gato_debug_write(self.h, name.encode(), _p(a), a.size))
+        a = self._f(arr).reshape(-1)
+        self._chk(self.L.gato_debug_write(self.h, name.encode(), self._p(a), a.size))
 
     def stage(self, stage, xu, timestep, x_s, ref):
-        xu = np.array(xu, dtype=np.float32, order="C").reshape(self.B, self.traj)
-        x_s = _f32(x_s, (self.B, self.nx))
-        ref = _f32(ref, (self.B, 6 * self.N))
-        _chk(load().gato_debug_stage(self.h, STAGES[stage], _p(xu), float(timestep), _p(x_s), _p(ref), None))
+        xu = np.array(xu, dtype=self.dtype, order="C").reshape(self.B, self.traj)
+        x_s = self._f(x_s, (self.B, self.nx))
+        ref = self._f(ref, (self.B, 6 * self.N))
+        self._chk(self.L.gato_debug_stage(self.h, STAGES[stage], self._p(xu), float(timestep), self._p(x_s), self._p(ref), None))
         return xu
 
     # expansion of the compact KKT storage into the reference's dense blocks (for stage comparisons)
     def dense_kkt(self, dt):
         B, N, nq, nx, nu = self.B, self.N, self.nq, self.nx, self.nu
         D = self.read("D").reshape(B, N, 3 * nq, nq)           # [c][r] col-major nq x 3nq
-        h2 = np.float32(0.5 * float(np.float32(dt)) * float(np.float32(dt)))
-        dtf = np.float32(dt)
-        A = np.zeros((B, N, nx, nx), np.float32)                # A[b,k,c,r] (col-major blocks like the reference's memory)
-        Bm = np.zeros((B, N, nu, nx), np.float32)
-        eye = np.eye(nq, dtype=np.float32)
+        h2 = self.dtype(0.5 * float(self.dtype(dt)) * float(self.dtype(dt)))
+        dtf = self.dtype(dt)
+        A = np.zeros((B, N, nx, nx), self.dtype)                # A[b,k,c,r] (col-major blocks like the reference's memory)
+        Bm = np.zeros((B, N, nu, nx), self.dtype)
+        eye = np.eye(nq, dtype=self.dtype)
         Dq, Dd, Mi = D[:, :, :nq], D[:, :, nq:2 * nq], D[:, :, 2 * nq:]
         A[:, :, :nq, :nq] = eye + h2 * Dq
         A[:, :, :nq, nq:] = dtf * Dq
@@ -331,14 +356,14 @@ class NativeSolver:
         Bm[:, N - 1] = 0
 
         def blk(qq, dd):
-            out = np.zeros((B, N, nx, nx), np.float32)
+            out = np.zeros((B, N, nx, nx), self.dtype)
             out[:, :, :nq, :nq] = qq.reshape(B, N, nq, nq)
             idx = np.arange(nq)
             out[:, :, nq + idx, nq + idx] = dd.reshape(B, N, nq)
             return out
 
         def dg(d):
-            out = np.zeros((B, N, nu, nu), np.float32)
+            out = np.zeros((B, N, nu, nu), self.dtype)
             idx = np.arange(nu)
             out[:, :, idx, idx] = d.reshape(B, N, nu)
             return out

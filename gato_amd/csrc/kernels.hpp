@@ -28,6 +28,7 @@
 
 #include <type_traits>
 
+#include "real.hpp"
 #include "rbd.hpp"
 
 namespace gato {
@@ -72,7 +73,7 @@ struct Buffers {
 #define GATO_DEV_EARLY __device__ __forceinline__
 GATO_DEV_EARLY Costs load_costs(const Buffers& bf, int b)
 {
-    const float4 lo = reinterpret_cast<const float4*>(bf.costw)[2 * b], hi = reinterpret_cast<const float4*>(bf.costw)[2 * b + 1];
+    const real4 lo = reinterpret_cast<const real4*>(bf.costw)[2 * b], hi = reinterpret_cast<const real4*>(bf.costw)[2 * b + 1];
     return Costs{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z};
 }
 
@@ -163,10 +164,10 @@ template<int CNT, int ALIGN> GATO_DEV void store_vec(float* __restrict__ dst, co
     constexpr int W = vec_width<CNT, ALIGN>();
     if constexpr (W == 4) {
 #pragma unroll
-        for (int i = 0; i < CNT / 4; i++) reinterpret_cast<float4*>(dst)[i] = make_float4(src[4 * i], src[4 * i + 1], src[4 * i + 2], src[4 * i + 3]);
+        for (int i = 0; i < CNT / 4; i++) reinterpret_cast<real4*>(dst)[i] = make_real4(src[4 * i], src[4 * i + 1], src[4 * i + 2], src[4 * i + 3]);
     } else if constexpr (W == 2) {
 #pragma unroll
-        for (int i = 0; i < CNT / 2; i++) reinterpret_cast<float2*>(dst)[i] = make_float2(src[2 * i], src[2 * i + 1]);
+        for (int i = 0; i < CNT / 2; i++) reinterpret_cast<real2*>(dst)[i] = make_real2(src[2 * i], src[2 * i + 1]);
     } else {
 #pragma unroll
         for (int i = 0; i < CNT; i++) dst[i] = src[i];
@@ -178,13 +179,13 @@ template<int CNT, int ALIGN> GATO_DEV void load_vec(float* dst, const float* __r
     if constexpr (W == 4) {
 #pragma unroll
         for (int i = 0; i < CNT / 4; i++) {
-            const float4 v = reinterpret_cast<const float4*>(src)[i];
+            const real4 v = reinterpret_cast<const real4*>(src)[i];
             dst[4 * i] = v.x; dst[4 * i + 1] = v.y; dst[4 * i + 2] = v.z; dst[4 * i + 3] = v.w;
         }
     } else if constexpr (W == 2) {
 #pragma unroll
         for (int i = 0; i < CNT / 2; i++) {
-            const float2 v = reinterpret_cast<const float2*>(src)[i];
+            const real2 v = reinterpret_cast<const real2*>(src)[i];
             dst[2 * i] = v.x; dst[2 * i + 1] = v.y;
         }
     } else {
@@ -326,7 +327,7 @@ GATO_DEV float merit_term(const Buffers& bf, const Costs& cw, int N, int b, int 
 
 template<class M, int NA>
 __global__ __launch_bounds__(256) void merit_kernel(Buffers bf, int N, int B, float dt, int use_dz, int sqp_iter, float thresh,
-                                                    float* __restrict__ out, float* __restrict__ out2, float4* __restrict__ zero4, uint32_t zero_n4)
+                                                    float* __restrict__ out, float* __restrict__ out2, real4* __restrict__ zero4, uint32_t zero_n4)
 {
     constexpr int NQ = M::NQ, NX = 2 * NQ, NU = NQ, KS = NX + NU;
     __shared__ float part[4];
@@ -337,7 +338,7 @@ __global__ __launch_bounds__(256) void merit_kernel(Buffers bf, int N, int B, fl
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     // the first launch of a solve also clears what bsqp.cuh:112-114 memsets (dz, PCG counts, convergence flags) and the device-side
     // loop control: nothing reads them before the next launch, and a fill launch of its own costs 2-4 us per solve
-    for (uint32_t i = g; i < zero_n4; i += gridDim.x * blockDim.x) zero4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (uint32_t i = g; i < zero_n4; i += gridDim.x * blockDim.x) zero4[i] = make_real4(0.f, 0.f, 0.f, 0.f);
     const int k = g % N, ai = (g / N) % NA;
     int b = g / (N * NA);
     const bool live = b < B;
@@ -607,7 +608,7 @@ __global__ __launch_bounds__(64 * ((M::NQ + 1) / 2 + 1), 2) void kkt_kernel(Buff
         const int cnt = (int)((total - first) < 64 ? (total - first) : 64);
         const int nfl = cnt * ND, n4 = nfl / 4;
         float* gD = bf.D + (size_t)first * ND;  // 64 ND floats per workgroup: 16-byte aligned
-        for (int i = threadIdx.x; i < n4; i += blockDim.x) reinterpret_cast<float4*>(gD)[i] = reinterpret_cast<const float4*>(ldsD)[i];
+        for (int i = threadIdx.x; i < n4; i += blockDim.x) reinterpret_cast<real4*>(gD)[i] = reinterpret_cast<const real4*>(ldsD)[i];
         for (int i = 4 * n4 + threadIdx.x; i < nfl; i += blockDim.x) gD[i] = ldsD[i];
     }
 }
@@ -694,7 +695,7 @@ GATO_DEV void schur_row0(const Buffers& bf, int N, int b, float rho, float* S, f
 template<int LPP, int O> GATO_DEV float group_bcast(float v)  // lane O of every group of LPP consecutive lanes
 {
     constexpr int ctrl = (LPP == 4) ? (O * 0x55) : (O | (O << 2) | ((2 + O) << 4) | ((2 + O) << 6));
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, false));
+    return dpp_get<ctrl>(v);
 }
 template<int LPP, int RW, int NX, int P> GATO_DEV void gj_coop_step(float (*W)[NX], int l, float rho_unused)
 {
@@ -1194,7 +1195,7 @@ __global__ __launch_bounds__(64) void schur2_kernel(Buffers bf, int N, int B, in
 // The two quotients of a PCG iteration (alpha = rho / pAp, beta = rho' / rho) as numerator x v_rcp_f32(denominator): 2 instructions
 // instead of the 12 of an IEEE division, on the per-wavefront instruction chain that bounds the launch.  v_rcp_f32 is good to 1 ulp;
 // the reference is built with -use_fast_math (CMakeLists.txt:22), whose division is the 2-ulp __fdividef.
-GATO_DEV float pcg_div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+GATO_DEV float pcg_div(float a, float b) { return a * fast_rcp(b); }
 
 template<int NXT> GATO_DEV float row_dot(const float* __restrict__ row, const float* __restrict__ win)
 {
@@ -1204,7 +1205,7 @@ template<int NXT> GATO_DEV float row_dot(const float* __restrict__ row, const fl
     if constexpr ((3 * NXT) % 4 == 0 && NXT % 4 == 0) {
 #pragma unroll
         for (int c = 0; c < 3 * NXT / 4; c++) {
-            const float4 v = reinterpret_cast<const float4*>(win)[c];
+            const real4 v = reinterpret_cast<const real4*>(win)[c];
             s0 += row[4 * c] * v.x;
             s1 += row[4 * c + 1] * v.y;
             s2 += row[4 * c + 2] * v.z;
@@ -1213,7 +1214,7 @@ template<int NXT> GATO_DEV float row_dot(const float* __restrict__ row, const fl
     } else {
 #pragma unroll
         for (int c = 0; c < 3 * NXT / 2; c++) {
-            const float2 v = reinterpret_cast<const float2*>(win)[c];
+            const real2 v = reinterpret_cast<const real2*>(win)[c];
             if (c & 1) { s2 += row[2 * c] * v.x; s3 += row[2 * c + 1] * v.y; }
             else { s0 += row[2 * c] * v.x; s1 += row[2 * c + 1] * v.y; }
         }
@@ -1225,7 +1226,7 @@ template<int NXT> GATO_DEV float row_dot(const float* __restrict__ row, const fl
 // row mirrors, then row_bcast15 / row_bcast31 accumulate the four 16-lane rows into lane 63, which is broadcast back.
 GATO_DEV float wave_sum(float v)
 {
-#define GATO_DPP_ADD(ctrl) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, false))
+#define GATO_DPP_ADD(ctrl) v += dpp_get<ctrl>(v)
     GATO_DPP_ADD(0xB1);   // quad_perm [1,0,3,2]
     GATO_DPP_ADD(0x4E);   // quad_perm [2,3,0,1]
     GATO_DPP_ADD(0x141);  // row_half_mirror
@@ -1233,10 +1234,10 @@ GATO_DEV float wave_sum(float v)
 #undef GATO_DPP_ADD
     // the four row sums through the scalar unit (independent v_readlane's) instead of two more dependent DPP steps:
     // 52 vs 59 ns per reduction in isolation (tools/microbench/wave_sum.hip)
-    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
-    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
-    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
-    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+    const float r0 = lane_read(v, 0);
+    const float r1 = lane_read(v, 16);
+    const float r2 = lane_read(v, 32);
+    const float r3 = lane_read(v, 48);
     return (r3 + r2) + (r1 + r0);   // the association of the row_bcast:15 / row_bcast:31 chain it replaces: same bits
 }
 
@@ -1248,13 +1249,13 @@ template<int PARTS = 4> GATO_DEV float block_sum(float v, float* part)
     v = wave_sum(v);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
     __syncthreads();
-    const float4 a = reinterpret_cast<const float4*>(part)[0];
+    const real4 a = reinterpret_cast<const real4*>(part)[0];
     float r = (a.x + a.y) + (a.z + a.w);
     if constexpr (PARTS == 1) return r;
-    const float4 b = reinterpret_cast<const float4*>(part)[1];
+    const real4 b = reinterpret_cast<const real4*>(part)[1];
     r = r + ((b.x + b.y) + (b.z + b.w));
     if constexpr (PARTS == 2) return r;
-    const float4 c = reinterpret_cast<const float4*>(part)[2], d = reinterpret_cast<const float4*>(part)[3];
+    const real4 c = reinterpret_cast<const real4*>(part)[2], d = reinterpret_cast<const real4*>(part)[3];
     return r + (((c.x + c.y) + (c.z + c.w)) + ((d.x + d.y) + (d.z + d.w)));
 }
 
@@ -1424,7 +1425,7 @@ __global__ __launch_bounds__(MAXT) void pcg_kernel(Buffers bf, int N, int B, uin
 // Packed FP32: each row keeps an (even, odd) pair of partial sums and advances it with v_pk_fma_f32 -- two FMAs per issued
 // instruction; the matrix rows already sit in consecutive registers and the window arrives as 16-byte LDS reads, so no packing
 // moves are needed.  The pair is added once at the end.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef real2 f32x2;   // a pair of reals: one v_pk_fma_f32 per fma in the fp32 build
 // Association of a row's 3 nx products (every register-resident PCG form shares it, so that they give the same bits): the row is cut
 // into two halves of 3 nx / 2 columns; each half accumulates its even and its odd columns in sequence (one packed FMA chain), and
 // the row sum is (even_lo + even_hi) + (odd_lo + odd_hi) -- the pair form of pcgc_kernel gives one half to each lane of a pair.
@@ -1439,7 +1440,7 @@ template<int NXT, int RPT, bool PACKED = true> GATO_DEV void rows_dot(const floa
         for (int u = 0; u < RPT; u++) e[0][u] = o[0][u] = e[1][u] = o[1][u] = 0.f;
 #pragma unroll
         for (int c = 0; c < 3 * NXT / 2; c++) {
-            const float2 v = reinterpret_cast<const float2*>(win)[c];
+            const real2 v = reinterpret_cast<const real2*>(win)[c];
             const int hf = (NXT % 4 == 0 && c >= HP) ? 1 : 0;
 #pragma unroll
             for (int u = 0; u < RPT; u++) {
@@ -1457,7 +1458,7 @@ template<int NXT, int RPT, bool PACKED = true> GATO_DEV void rows_dot(const floa
         for (int u = 0; u < RPT; u++) a2[0][u] = a2[1][u] = f32x2{0.f, 0.f};
 #pragma unroll
         for (int c = 0; c < 3 * NXT / 4; c++) {
-            const float4 v = reinterpret_cast<const float4*>(win)[c];
+            const real4 v = reinterpret_cast<const real4*>(win)[c];
             const f32x2 lo = {v.x, v.y}, hi = {v.z, v.w};
 #pragma unroll
             for (int u = 0; u < RPT; u++) {
@@ -1478,7 +1479,7 @@ template<int NXT, int RPT, bool PACKED = true> GATO_DEV void rows_dot(const floa
         for (int u = 0; u < RPT; u++) a2[u] = f32x2{0.f, 0.f};
 #pragma unroll
         for (int c = 0; c < 3 * NXT / 2; c++) {
-            const float2 v = reinterpret_cast<const float2*>(win)[c];
+            const real2 v = reinterpret_cast<const real2*>(win)[c];
             const f32x2 w = {v.x, v.y};
 #pragma unroll
             for (int u = 0; u < RPT; u++) a2[u] = __builtin_elementwise_fma(f32x2{rows[u][2 * c], rows[u][2 * c + 1]}, w, a2[u]);
@@ -1488,9 +1489,9 @@ template<int NXT, int RPT, bool PACKED = true> GATO_DEV void rows_dot(const floa
     }
 }
 
-// Same dot products with the rows' RIGHT block (the last nx entries) parked in LDS as float4 [chunk][thread] (conflict-free): the
+// Same dot products with the rows' RIGHT block (the last nx entries) parked in LDS as real4 [chunk][thread] (conflict-free): the
 // iteration loop then needs nx x RPT fewer registers.  Only for nx % 4 == 0.
-template<int NXT, int RPT> GATO_DEV void rows_dot_parked(const float (*rows)[3 * NXT], const float* __restrict__ win, const float4* park, int T,
+template<int NXT, int RPT> GATO_DEV void rows_dot_parked(const float (*rows)[3 * NXT], const float* __restrict__ win, const real4* park, int T,
                                                          float* acc)
 {
     static_assert(NXT % 4 == 0, "16-byte chunks");
@@ -1501,7 +1502,7 @@ template<int NXT, int RPT> GATO_DEV void rows_dot_parked(const float (*rows)[3 *
     for (int u = 0; u < RPT; u++) a2[0][u] = a2[1][u] = f32x2{0.f, 0.f};
 #pragma unroll
     for (int c = 0; c < 2 * CH; c++) {
-        const float4 v = reinterpret_cast<const float4*>(win)[c];
+        const real4 v = reinterpret_cast<const real4*>(win)[c];
         const f32x2 lo = {v.x, v.y}, hi = {v.z, v.w};
 #pragma unroll
         for (int u = 0; u < RPT; u++) {
@@ -1513,11 +1514,11 @@ template<int NXT, int RPT> GATO_DEV void rows_dot_parked(const float (*rows)[3 *
     }
 #pragma unroll
     for (int c = 0; c < CH; c++) {
-        const float4 v = reinterpret_cast<const float4*>(win)[2 * CH + c];
+        const real4 v = reinterpret_cast<const real4*>(win)[2 * CH + c];
         const f32x2 lo = {v.x, v.y}, hi = {v.z, v.w};
 #pragma unroll
         for (int u = 0; u < RPT; u++) {
-            const float4 m = park[(u * CH + c) * T];
+            const real4 m = park[(u * CH + c) * T];
             a2[1][u] = __builtin_elementwise_fma(f32x2{m.x, m.y}, lo, a2[1][u]);   // the right block lies in the upper half (2 nx >= 3 nx / 2)
             a2[1][u] = __builtin_elementwise_fma(f32x2{m.z, m.w}, hi, a2[1][u]);
         }
@@ -1543,10 +1544,10 @@ template<int NXT, int RPT> GATO_DEV void rows_dot_parked(const float (*rows)[3 *
 template<int PM> GATO_DEV float pair_partner(float p)
 {
     if constexpr (PM == 0) {
-        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, p), 0xB1, 0xf, 0xf, false));
+        return dpp_get<0xB1>(p);
     } else {
-        const int a = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, p), 0x104, 0xf, 0x5, false);
-        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(a, __builtin_bit_cast(int, p), 0x114, 0xf, 0xA, false));
+        const float a = dpp_mov<0x104, 0xf, 0x5>((float)0, p);
+        return dpp_mov<0x114, 0xf, 0xA>(a, p);
     }
 }
 template<int HC, int RPT, int PM = 0> GATO_DEV void rows_dot_half(const float (*rows)[HC], const float* w, float* acc)
@@ -1572,7 +1573,7 @@ template<int HC> GATO_DEV void load_half_window(float* w, const float* __restric
 {
 #pragma unroll
     for (int c = 0; c < HC / 2; c++) {
-        const float2 v = reinterpret_cast<const float2*>(win)[c];
+        const real2 v = reinterpret_cast<const real2*>(win)[c];
         w[2 * c] = v.x;
         w[2 * c + 1] = v.y;
     }
@@ -1581,21 +1582,21 @@ template<int HC> GATO_DEV void load_half_window(float* w, const float* __restric
 // a lane to its partner is left out (PM = 0: quad_perm [1,0,3,2]; PM = 1: row_half_mirror, which adds the two quads of an 8-lane group)
 template<int PM = 0> GATO_DEV float wave_sum_pairs(float v)
 {
-#define GATO_DPP_ADD(ctrl) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, false))
+#define GATO_DPP_ADD(ctrl) v += dpp_get<ctrl>(v)
     if constexpr (PM == 1) GATO_DPP_ADD(0xB1);   // quad_perm [1,0,3,2]
     GATO_DPP_ADD(0x4E);                           // quad_perm [2,3,0,1]
     if constexpr (PM == 0) GATO_DPP_ADD(0x141);  // row_half_mirror
     GATO_DPP_ADD(0x140);                          // row_mirror
 #undef GATO_DPP_ADD
-    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
-    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
-    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
-    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+    const float r0 = lane_read(v, 0);
+    const float r1 = lane_read(v, 16);
+    const float r2 = lane_read(v, 32);
+    const float r3 = lane_read(v, 48);
     return (r3 + r2) + (r1 + r0);
 }
 GATO_DEV float read_parts(const float* part)   // <= 4 wavefront partials
 {
-    const float4 a = reinterpret_cast<const float4*>(part)[0];
+    const real4 a = reinterpret_cast<const real4*>(part)[0];
     return (a.x + a.y) + (a.z + a.w);
 }
 
@@ -1787,15 +1788,15 @@ __global__ __launch_bounds__(MAXT) void pcgc_kernel(Buffers bf, int N, int B, ui
         }
         // PARK: the right blocks of the P^-1 rows move to the LDS the fold no longer needs
         constexpr bool PARK = FUSE && FOLD && (NX % 4 == 0) && !PAIR;
-        const float4* park = nullptr;
+        const real4* park = nullptr;
         if constexpr (PARK) {
-            float4* pk = reinterpret_cast<float4*>(partB + 16) + threadIdx.x;
+            real4* pk = reinterpret_cast<real4*>(partB + 16) + threadIdx.x;
             __syncthreads();  // the fold's last readers of bufA are done
 #pragma unroll
             for (int u = 0; u < RPT; u++)
 #pragma unroll
                 for (int c = 0; c < NX / 4; c++)
-                    pk[(u * (NX / 4) + c) * blockDim.x] = make_float4(Prow[u][2 * NX + 4 * c], Prow[u][2 * NX + 4 * c + 1], Prow[u][2 * NX + 4 * c + 2],
+                    pk[(u * (NX / 4) + c) * blockDim.x] = make_real4(Prow[u][2 * NX + 4 * c], Prow[u][2 * NX + 4 * c + 1], Prow[u][2 * NX + 4 * c + 2],
                                                                       Prow[u][2 * NX + 4 * c + 3]);
             park = pk;
         }
@@ -1806,7 +1807,7 @@ __global__ __launch_bounds__(MAXT) void pcgc_kernel(Buffers bf, int N, int B, ui
             // its S and P^-1 rows: per product 27 packed FMAs behind 9 ds_read_b64 that are all in flight at once; two DPP moves
             // fetch the partner's half sum, and the wavefront sum leaves out the butterfly that would add a lane to its partner.
             constexpr int HC = BR / 2;
-            static_assert(BR % 4 == 0, "halves are whole float2 pairs");
+            static_assert(BR % 4 == 0, "halves are whole real2 pairs");
             const int h = (threadIdx.x >> 2) & 1;
             const bool owner = have && h == 0;   // the lane of the pair that publishes the pair's vector entries
             float Sh[RPT][HC], Ph[RPT][HC];
@@ -1986,14 +1987,14 @@ __global__ __launch_bounds__(MAXT) void pcgc_kernel(Buffers bf, int N, int B, ui
 // Per matrix-vector product: vector -> LDS | barrier | both roles work, the left role leaves its row partials and transposed partials in
 // LDS, every wavefront its share of v^T Mx v | barrier | the main role adds  main + left + (two halves of the transposed partial of
 // block k+1), everybody sums the wavefront shares: 4 barriers per PCG iteration.  Four rows of every thread's
-// P^-1 block live in LDS (float4 [nx][T], conflict-free) to stay under 256 registers.  Sums associate as (main + left) + t0 + t1; the
+// P^-1 block live in LDS (real4 [nx][T], conflict-free) to stay under 256 registers.  Sums associate as (main + left) + t0 + t1; the
 // reference sums a row's 3 nx terms in sequence (linalg.cuh:174-260) -- the same fp32 freedom the other PCG kernels take (even / odd
 // pairs).  Needs the COMPLETE P^-1 in global memory (schur2_kernel) and N >= 16 (whole wavefronts).
 // One thread's HR x NX block times the window w (row dots) and -- TR -- its transpose times the
-// thread's own HR vector entries vo (tp[j] = sum_i Mt[i][j] vo[i]).  The first NP rows of the block are parked in LDS as float4 chunks
+// thread's own HR vector entries vo (tp[j] = sum_i Mt[i][j] vo[i]).  The first NP rows of the block are parked in LDS as real4 chunks
 // [c][T] and streamed through four registers at a time; rows NP.. sit in Mt[0 .. HR-NP).
 template<int NX, int HR, int NP, bool TR>
-GATO_DEV void half_block(const float (*Mt)[NX], const float4* park, int T, const float* w, const float* vo, float* acc, float* tp)
+GATO_DEV void half_block(const float (*Mt)[NX], const real4* park, int T, const float* w, const float* vo, float* acc, float* tp)
 {
     // packed FP32 (v_pk_fma_f32): row dots keep an (even, odd) pair of partial sums per row, the transposed accumulate advances two
     // adjacent columns with the row's vector entry in both halves
@@ -2007,7 +2008,7 @@ GATO_DEV void half_block(const float (*Mt)[NX], const float4* park, int T, const
     if constexpr (NP > 0) {
 #pragma unroll
         for (int c = 0; c < (NP * NX) / 4; c++) {
-            const float4 m4 = park[c * T];
+            const real4 m4 = park[c * T];
             const f32x2 m[2] = {f32x2{m4.x, m4.y}, f32x2{m4.z, m4.w}};
 #pragma unroll
             for (int q = 0; q < 2; q++) {
@@ -2044,7 +2045,7 @@ __global__ __launch_bounds__(MAXT, 2) void pcgs_kernel(Buffers bf, int N, int B,
 {
     constexpr int NQ = M::NQ, NX = 2 * NQ, HR = NX / 2, BR = 3 * NX, BROW = 3 * NX * NX;
     constexpr int NP = 4;                      // rows of the thread's P^-1 block parked in LDS
-    constexpr int PF4 = (NP * NX) / 4;         // as float4 chunks
+    constexpr int PF4 = (NP * NX) / 4;         // as real4 chunks
     static_assert(NX % 2 == 0 && (NP * NX) % 4 == 0, "layout");
     constexpr int PARTS = MAXT <= 256 ? 1 : 2;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -2057,7 +2058,7 @@ __global__ __launch_bounds__(MAXT, 2) void pcgs_kernel(Buffers bf, int N, int B,
     float* partB = partA + 16;
     float* rowbuf = partB + 16;                // [N nx]: the left-block part of every row's product
     float* tbuf = rowbuf + N * NX;             // [N + 1][2][nx]: transposed partials of block k, by row half; block N stays zero
-    float4* park = reinterpret_cast<float4*>(tbuf + (N + 1) * 2 * NX) + t;  // [PF4][T]
+    real4* park = reinterpret_cast<real4*>(tbuf + (N + 1) * 2 * NX) + t;  // [PF4][T]
     if (t < 32) partA[t] = 0.f;  // partA and partB are adjacent: slots of wavefronts the workgroup does not have stay zero
     const float abs_tol = 1e-6f;
     uint32_t iters = 0;
@@ -2146,7 +2147,7 @@ __global__ __launch_bounds__(MAXT, 2) void pcgs_kernel(Buffers bf, int N, int B,
             }
 #pragma unroll
             for (int c = 0; c < PF4; c++)
-                park[c * T] = make_float4((&Pf[0][0])[4 * c], (&Pf[0][0])[4 * c + 1], (&Pf[0][0])[4 * c + 2], (&Pf[0][0])[4 * c + 3]);
+                park[c * T] = make_real4((&Pf[0][0])[4 * c], (&Pf[0][0])[4 * c + 1], (&Pf[0][0])[4 * c + 2], (&Pf[0][0])[4 * c + 3]);
 #pragma unroll
             for (int i = NP; i < HR; i++)
 #pragma unroll
@@ -2207,10 +2208,10 @@ __global__ __launch_bounds__(MAXT, 2) void pcgs_kernel(Buffers bf, int N, int B,
 #pragma unroll
                 for (int i = 0; i < HR; i++) out[i] = 0.f;
             }
-            const float4 pa = reinterpret_cast<const float4*>(part)[0];
+            const real4 pa = reinterpret_cast<const real4*>(part)[0];
             float tot = (pa.x + pa.y) + (pa.z + pa.w);
             if constexpr (PARTS == 2) {
-                const float4 pb = reinterpret_cast<const float4*>(part)[1];
+                const real4 pb = reinterpret_cast<const real4*>(part)[1];
                 tot = tot + ((pb.x + pb.y) + (pb.z + pb.w));
             }
             return tot;
@@ -2284,12 +2285,12 @@ __global__ __launch_bounds__(MAXT, 2) void pcgs_kernel(Buffers bf, int N, int B,
 // =========================================================================================================================
 template<int PC> GATO_DEV float quad_bcast(float v)  // lane PC of every quad
 {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), PC * 0x55, 0xf, 0xf, false));
+    return dpp_get<PC * 0x55>(v);
 }
 GATO_DEV float quad_sum(float v)
 {
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));  // quad_perm [1,0,3,2]
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));  // quad_perm [2,3,0,1]
+    v += dpp_get<0xB1>(v);  // quad_perm [1,0,3,2]
+    v += dpp_get<0x4E>(v);  // quad_perm [2,3,0,1]
     return v;
 }
 // one Gauss-Jordan pivot of the distributed block: D[i] = entry (r, cq CW + i); P is a compile-time constant.  In place: column P of
@@ -2301,9 +2302,9 @@ template<int NX, int CW, int P> GATO_DEV void gj_quad_step(float* D, int r, int 
     float prow[CW];
 #pragma unroll
     for (int i = 0; i < CW; i++)              // row P, this lane's columns: lane 4 P + cq (ds_bpermute takes a byte address)
-        prow[i] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(baddr + 16 * P, __builtin_bit_cast(int, D[i])));
-    const float ppiv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, D[PI]), P * 4 + PC));  // entry (P, P)
-    const float pvInv = __builtin_amdgcn_rcpf(ppiv);
+        prow[i] = lane_permute(baddr + 16 * P, D[i]);
+    const float ppiv = lane_read(D[PI], P * 4 + PC);  // entry (P, P)
+    const float pvInv = fast_rcp(ppiv);
     const float f = quad_bcast<PC>(D[PI]) * pvInv;                                                                    // entry (r, P) / pivot
     const bool owner = (r == P);
 #pragma unroll

@@ -15,6 +15,14 @@
 #include <string>
 #include <vector>
 
+// -DGATO_DOUBLE: the USE_DOUBLES build of the binding (python/bindings.cu:244-252) -- module _gato_ext_f64 over libgato_hip_f64.so; every
+// `float` below (numpy dtypes included) is the library's real type
+#ifdef GATO_DOUBLE
+#define float double
+#define GATO_EXT_NAME _gato_ext_f64
+#else
+#define GATO_EXT_NAME _gato_ext
+#endif
 #include "../../include/gato_abi.h"
 
 namespace py = pybind11;
@@ -203,7 +211,7 @@ class PyBSQP {
     int N_ = 0, B_ = 0, nq_ = 0, nx_ = 0, nu_ = 0, traj_ = 0;
 };
 
-PYBIND11_MODULE(_gato_ext, m)
+PYBIND11_MODULE(GATO_EXT_NAME, m)
 {
     m.doc() = "MI355X-native batched SQP solver (pybind11 over the C ABI of libgato_hip.so); replaces python/bindings.cu";
     m.attr("version") = gato_version();
@@ -223,7 +231,7 @@ PYBIND11_MODULE(_gato_ext, m)
         }
         return py::make_tuple(R, p);
     });
-    py::class_<PyBSQP>(m, "BSQP")
+    py::class_<PyBSQP>(m, "BSQP", py::module_local())
         .def(py::init<const std::string&, int, int>(), py::arg("plant"), py::arg("knot_points"), py::arg("batch_size"))
         .def(py::init<const std::string&, int, int, float, uint32_t, float, uint32_t, float, float, float, float, float, float, float, float, float, float, float>(),
              py::arg("plant"), py::arg("knot_points"), py::arg("batch_size"), py::arg("dt"), py::arg("max_sqp_iters"), py::arg("kkt_tol"),

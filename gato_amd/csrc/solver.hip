@@ -11,8 +11,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <vector>
 
+#include "real.hpp"   // GATO_DOUBLE: `float` is the real type from here on (the ABI below included)
 #include "../../include/gato_abi.h"
 #include "kernels.hpp"
 
@@ -255,10 +257,10 @@ template<class M> static void launch_merit(GatoSolver* s, hipStream_t st, int na
     const long n = (long)s->B * na * s->N;
     if (na == 1)
         hipLaunchKernelGGL((merit_kernel<M, 1>), dim3(cdiv(n, 256)), dim3(256), 0, st, s->bf, s->N, s->B, dt, use_dz, sqp_iter, thresh, out, out2,
-                           reinterpret_cast<float4*>(zero), (uint32_t)(zero_words / 4));
+                           reinterpret_cast<real4*>(zero), (uint32_t)(zero_words / 4));
     else
         hipLaunchKernelGGL((merit_kernel<M, NUM_ALPHAS>), dim3(cdiv(n, 256)), dim3(256), 0, st, s->bf, s->N, s->B, dt, use_dz, sqp_iter,
-                           thresh, out, (float*)nullptr, (float4*)nullptr, 0u);
+                           thresh, out, (float*)nullptr, (real4*)nullptr, 0u);
 }
 template<class M> static void launch_kkt(GatoSolver* s, hipStream_t st, float dt, int sqp_iter, int row0 = 0)
 {
@@ -315,7 +317,7 @@ template<class M, int RPT, int FORCE_WPS = 0> static bool pcgc_grant_fold(const 
 }
 template<class M> static size_t pcg_fused_lds(const GatoSolver* s)
 {
-    // LDS behind the vectors: the two fold buffers [N][nx][nx], later reused to park 3 x nx/4 float4 per thread (the larger for N < 8,
+    // LDS behind the vectors: the two fold buffers [N][nx][nx], later reused to park 3 x nx/4 real4 per thread (the larger for N < 8,
     // where the workgroup is padded to one wavefront)
     constexpr int NX = 2 * M::NQ;
     const int T = PcgcShape<NX, 3, 0>::threads(s->N * s->nx);
@@ -324,11 +326,11 @@ template<class M> static size_t pcg_fused_lds(const GatoSolver* s)
 }
 
 // pcgs_kernel: 4 N threads; LDS = the two vectors + partial sums + row partials [N nx] + transposed partials [(N+1) 2 nx] + four parked rows
-// of every thread's P^-1 block (float4 [nx][T])
+// of every thread's P^-1 block (real4 [nx][T])
 static size_t pcgs_lds(const GatoSolver* s)
 {
     const size_t T = 4 * (size_t)s->N, nx = s->nx;
-    return ((size_t)2 * s->vecp + 36 + (size_t)s->N * nx + (size_t)(s->N + 1) * 2 * nx) * sizeof(float) + (4 * nx / 4) * T * 16;
+    return ((size_t)2 * s->vecp + 36 + (size_t)s->N * nx + (size_t)(s->N + 1) * 2 * nx) * sizeof(float) + (4 * nx / 4) * T * sizeof(real4);
 }
 template<class M> static bool pcgs_grant(const GatoSolver* s)
 {
@@ -603,10 +605,10 @@ static void collect_profile(GatoSolver* s)
     if (!s->profiling || s->events.size() < 2) return;
     memset(s->stage_us, 0, sizeof(s->stage_us));
     for (size_t i = 1; i < s->events.size(); i++) {
-        float ms = 0.f;
+        f32_t ms = 0;
         if (hipEventElapsedTime(&ms, s->events[i - 1], s->events[i]) == hipSuccess && s->event_stage[i] >= 0) s->stage_us[s->event_stage[i]] += ms * 1e3;
     }
-    float ms = 0.f;
+    f32_t ms = 0;
     if (hipEventElapsedTime(&ms, s->events.front(), s->events.back()) == hipSuccess) s->stage_us[ST_COUNT] = ms * 1e3;
 }
 

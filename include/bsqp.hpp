@@ -1,11 +1,12 @@
 // bsqp.hpp -- the reference's C++ solver API `template<typename T, uint32_t BatchSize> class BSQP` (gato/bsqp/bsqp.cuh:20-197) and its
 // companion structs (gato/types.cuh:13-59) as a header-only wrapper over the C ABI of libgato_hip.so, so that the reference's
-// C++ example (examples/bsqp.cu:7-77) compiles against this library after its cuda* -> hip* renames.  float only (the C ABI is
-// fp32 like the reference's default `typedef float T`, settings.h:7-11).
+// C++ example (examples/bsqp.cu:7-77) compiles against this library after its cuda* -> hip* renames.  T = float with libgato_hip.so (the reference's
+// default `typedef float T`, settings.h:7-11), T = double with -DGATO_DOUBLE and libgato_hip_f64.so (its USE_DOUBLES).
 //
 // Plant and horizon are template/ctor arguments here instead of -D defines: BSQP<float, 16> solver(GATO_PLANT_INDY7, 16, dt, ...).
 // If GATO_PLANT and KNOT_POINTS macros are defined (the reference's build convention) they are the defaults.
 #pragma once
+#include <type_traits>
 #include <chrono>
 #include <cstdint>
 #include <stdexcept>
@@ -57,7 +58,7 @@ struct SQPStats {  // gato/types.cuh:46-59
 
 template<typename T, uint32_t BatchSize>
 class BSQP {
-    static_assert(sizeof(T) == sizeof(float), "libgato_hip is fp32");
+    static_assert(std::is_same<T, gato_real>::value, "T must be the library's real type: float with libgato_hip.so, double with -DGATO_DOUBLE and libgato_hip_f64.so");
 
   public:
     BSQP(int plant = GATO_PLANT, int knot_points = KNOT_POINTS)

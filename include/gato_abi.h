@@ -7,7 +7,11 @@
  * and gato_last_error() gives the text.  Plant and horizon are run-time parameters here (the reference bakes them in at
  * compile time: -DPLANT_* -DKNOT_POINTS, CMakeLists.txt:57-83); the batch size is run-time too (template parameter there).
  *
- * Layouts are the reference's (gato/utils/linalg.cuh:545-672), all float32, C-contiguous:
+ * Real type: `gato_real` = float in libgato_hip.so (the reference's default `typedef float T`, gato/settings.h:7-11); compiled with
+ * -DGATO_DOUBLE -- the reference's USE_DOUBLES -- the same sources give libgato_hip_f64.so with the same entry points on double
+ * buffers (a validation mode, as in the reference: python/bindings.cu:244-252 registers double classes up to batch 128 only).
+ *
+ * Layouts are the reference's (gato/utils/linalg.cuh:545-672), all gato_real, C-contiguous:
  *   xu    [B][TRAJ]      TRAJ = (nx+nu) N - nu, knot = [x_k (nx), u_k (nu)], last knot x only
  *   x_s   [B][nx]        nx = 2 nq, nu = nq  (indy7 nq = 6, iiwa14 nq = 7)
  *   ref   [B][N][6]      end-effector reference, xyz + 3 unused
@@ -29,6 +33,12 @@ extern "C" {
 #define GATO_ERR_HIP (-2)       /* a HIP runtime call failed; see gato_last_error() */
 #define GATO_ERR_NO_DEVICE (-3) /* no gfx950-capable device visible */
 
+#ifdef GATO_DOUBLE
+typedef double gato_real;
+#else
+typedef float gato_real;
+#endif
+
 #define GATO_PLANT_INDY7 0
 #define GATO_PLANT_IIWA14 1
 
@@ -36,15 +46,15 @@ typedef struct GatoSolver GatoSolver;
 
 /* The 15 scalars of BSQP's second constructor, in its order (gato/bsqp/bsqp.cuh:43-45; python/bindings.cu:35-56). */
 typedef struct GatoParams {
-    float dt;
+    gato_real dt;
     uint32_t max_sqp_iters;
-    float kkt_tol; /* accepted and unused, as in the reference (bsqp.cuh:153) */
+    gato_real kkt_tol; /* accepted and unused, as in the reference (bsqp.cuh:153) */
     uint32_t max_pcg_iters;
-    float pcg_tol;
-    float solve_ratio;
-    float mu;
-    float q_cost, qd_cost, u_cost, N_cost, q_lim_cost, vel_lim_cost, ctrl_lim_cost;
-    float rho;
+    gato_real pcg_tol;
+    gato_real solve_ratio;
+    gato_real mu;
+    gato_real q_cost, qd_cost, u_cost, N_cost, q_lim_cost, vel_lim_cost, ctrl_lim_cost;
+    gato_real rho;
 } GatoParams;
 
 /* Fills *p with the defaults of BSQP's first constructor (bsqp.cuh:24-27). */
@@ -62,11 +72,11 @@ int gato_destroy(GatoSolver* s);
 /* PyBSQP::solve (python/bindings.cu:68-148) with host buffers: H2D of xu, x_s, ref; BSQP::solve; D2H of xu.
  * xu is updated in place.  sqp_time_us (may be NULL) receives the host wall time of the device-synchronised SQP loop with the
  * reference's meaning (bsqp.cuh:109,185,190: copies excluded). */
-int gato_solve(GatoSolver* s, float* xu, float timestep, const float* x_s, const float* ref, double* sqp_time_us);
+int gato_solve(GatoSolver* s, gato_real* xu, gato_real timestep, const gato_real* x_s, const gato_real* ref, double* sqp_time_us);
 
 /* BSQP::solve (bsqp.cuh:103-197) on device pointers, enqueued on `stream` (a hipStream_t, NULL = default stream) WITHOUT a host
  * synchronisation: the caller synchronises the stream before reading d_xu or calling the gato_get_* functions. */
-int gato_solve_device(GatoSolver* s, float* d_xu, float timestep, const float* d_x_s, const float* d_ref, void* stream);
+int gato_solve_device(GatoSolver* s, gato_real* d_xu, gato_real timestep, const gato_real* d_x_s, const gato_real* d_ref, void* stream);
 
 /* Waits for the solve in flight on the stream of the last gato_solve_device call (no-op when there is none). */
 int gato_synchronize(GatoSolver* s);
@@ -74,7 +84,7 @@ int gato_synchronize(GatoSolver* s);
 /* Stream-ordered variants for callers that keep everything on one HIP stream (bench.py, the multi-GPU layer): the resets of
  * bsqp.cuh:81-87 as device-side copies enqueued on `stream`, and the final merits copied device-to-device into d_out [B]. */
 int gato_reset_async(GatoSolver* s, int reset_dual, int reset_rho, void* stream);
-int gato_copy_final_merit_device(GatoSolver* s, float* d_out, void* stream);
+int gato_copy_final_merit_device(GatoSolver* s, gato_real* d_out, void* stream);
 
 /* Statistics of the last solve = the fields of SQPStats / the result dict of PyBSQP::solve (gato/types.cuh:23-59,
  * python/bindings.cu:96-145).  Synchronises the solver's last stream.
@@ -83,22 +93,22 @@ int gato_copy_final_merit_device(GatoSolver* s, float* d_out, void* stream);
 int gato_get_counts(GatoSolver* s, uint32_t* iters_done, uint32_t* ls_num_iters);
 int gato_get_sqp_iters(GatoSolver* s, int32_t* out /* [B] */);
 int gato_get_kkt_converged(GatoSolver* s, int32_t* out /* [B] */);
-int gato_get_final_merit(GatoSolver* s, float* out /* [B] */);   /* BSQP::copy_final_merit_to_host, bsqp.cuh:93-96 */
-int gato_get_initial_merit(GatoSolver* s, float* out /* [B] */); /* BSQP::copy_initial_merit0_to_host, bsqp.cuh:98-101 */
+int gato_get_final_merit(GatoSolver* s, gato_real* out /* [B] */);   /* BSQP::copy_final_merit_to_host, bsqp.cuh:93-96 */
+int gato_get_initial_merit(GatoSolver* s, gato_real* out /* [B] */); /* BSQP::copy_initial_merit0_to_host, bsqp.cuh:98-101 */
 int gato_get_pcg_iters(GatoSolver* s, int32_t* out /* [iters_done][B] */);
-int gato_get_ls_min_merit(GatoSolver* s, float* out /* [ls_num_iters][B] */);
-int gato_get_ls_step_size(GatoSolver* s, float* out /* [ls_num_iters][B] */);
+int gato_get_ls_min_merit(GatoSolver* s, gato_real* out /* [ls_num_iters][B] */);
+int gato_get_ls_step_size(GatoSolver* s, gato_real* out /* [ls_num_iters][B] */);
 
 /* Setters, host arrays of length B (6 B for the wrench): bsqp.cuh:63-89. */
-int gato_set_f_ext_batch(GatoSolver* s, const float* f_ext);
-int gato_set_rho_penalty_batch(GatoSolver* s, const float* rho, int set_as_reset_default);
-int gato_set_drho_batch(GatoSolver* s, const float* drho, int set_as_reset_default);
-int gato_set_mu_batch(GatoSolver* s, const float* mu);
-int gato_set_pcg_tol_batch(GatoSolver* s, const float* pcg_tol);
+int gato_set_f_ext_batch(GatoSolver* s, const gato_real* f_ext);
+int gato_set_rho_penalty_batch(GatoSolver* s, const gato_real* rho, int set_as_reset_default);
+int gato_set_drho_batch(GatoSolver* s, const gato_real* drho, int set_as_reset_default);
+int gato_set_mu_batch(GatoSolver* s, const gato_real* mu);
+int gato_set_pcg_tol_batch(GatoSolver* s, const gato_real* pcg_tol);
 /* EXTENSION beyond the reference API ("per-trajectory cost weights"): w[B][7] = q_cost, qd_cost, u_cost, N_cost,
  * q_lim_cost, vel_lim_cost, ctrl_lim_cost of each trajectory; generalises the scalar weights of the constructor (bsqp.cuh:344-350),
  * which every trajectory has until this is called.  A hyper-parameter sweep (gato_hparam_batch.ipynb) then is ONE batch. */
-int gato_set_cost_weights_batch(GatoSolver* s, const float* w);
+int gato_set_cost_weights_batch(GatoSolver* s, const gato_real* w);
 int gato_reset_dual(GatoSolver* s);
 int gato_reset_rho(GatoSolver* s);
 int gato_set_rho_adaptation(GatoSolver* s, int enabled);
@@ -116,41 +126,41 @@ int gato_set_linear_solver(GatoSolver* s, int mode);
 
 /* BSQP::sim_forward / PyBSQP::sim_forward (bsqp.cuh:91, bindings.cu:180-194): one integrator step of the SHARED (xk, uk) under the
  * B stored wrench hypotheses; xkp1 is [B][nx] on the host. */
-int gato_sim_forward(GatoSolver* s, float* xkp1, const float* xk, const float* uk, float dt);
+int gato_sim_forward(GatoSolver* s, gato_real* xkp1, const gato_real* xk, const gato_real* uk, gato_real dt);
 /* BSQP::sim_forward(T* d_xkp1_batch, T* d_xk, T* d_uk, T dt) itself (bsqp.cuh:91, kernel sim.cuh:14-49): device pointers
  * (d_xkp1 [B][nx], d_xk [nx], d_uk [nu]), enqueued on `stream` without a host synchronisation. */
-int gato_sim_forward_device(GatoSolver* s, float* d_xkp1, const float* d_xk, const float* d_uk, float dt, void* stream);
+int gato_sim_forward_device(GatoSolver* s, gato_real* d_xkp1, const gato_real* d_xk, const gato_real* d_uk, gato_real dt, void* stream);
 
 /* Hypothesis selection of the MPC loop, MPC_GATO.evaluate_best_trajectory (python/bsqp/mpc_controller.py:294-309), in one launch:
  * sim_forward of the shared (x_last, u_last) under the B stored wrenches, errors[b] = |x_next_b - x_meas|_2 and *best = the first
  * arg-min (np.argmin).  errors ([B], host) may be NULL.  The _device form takes device pointers, is enqueued on `stream` and does not
  * synchronise; d_best is one int32. */
-int gato_select_best(GatoSolver* s, const float* x_last, const float* u_last, const float* x_meas, float dt, int* best, float* errors);
-int gato_select_best_device(GatoSolver* s, const float* d_x_last, const float* d_u_last, const float* d_x_meas, float dt, int32_t* d_best,
-                            float* d_errors, void* stream);
+int gato_select_best(GatoSolver* s, const gato_real* x_last, const gato_real* u_last, const gato_real* x_meas, gato_real dt, int* best, gato_real* errors);
+int gato_select_best_device(GatoSolver* s, const gato_real* d_x_last, const gato_real* d_u_last, const gato_real* d_x_meas, gato_real dt, int32_t* d_best,
+                            gato_real* d_errors, void* stream);
 
 /* The plant of the closed MPC loop (python/bsqp/common.py:49-91 `rk4` over pinocchio's aba, stepped at 1 kHz by
  * mpc_controller.py:199-218), on the library's own forward dynamics: nsteps RK4 steps of size sim_dt from x ([nx], host, updated in
  * place) with control u_seq[step] ([nsteps][nu], host) under the constant spatial wrench f_ext6 = [angular; linear] acting on the
  * last link, expressed in that link's frame. */
-int gato_plant_rk4(GatoSolver* s, float* x, const float* u_seq, int nsteps, const float* f_ext6, float sim_dt);
+int gato_plant_rk4(GatoSolver* s, gato_real* x, const gato_real* u_seq, int nsteps, const gato_real* f_ext6, gato_real sim_dt);
 /* World placements of the nq joint frames (pinocchio's data.oMi[1..nq] in mpc_controller.py:311-338) from the library's own
  * kinematic tables: out[k] = {R row-major (9 doubles), p (3 doubles)}.  Host-only, no device needed. */
-int gato_fk_placements(int plant, const float* q, double* out);
+int gato_fk_placements(int plant, const gato_real* q, double* out);
 
 /* End-effector positions [n][3] of n joint configurations [n][nq] (host arrays): what interface.BSQP.ee_pos obtains from
  * pinocchio in the reference (python/bsqp/interface.py:212-214), computed with the solver's own kinematics. */
-int gato_ee_pos(GatoSolver* s, const float* q, int n, float* out);
+int gato_ee_pos(GatoSolver* s, const gato_real* q, int n, gato_real* out);
 
 /* Debug / test access to a device buffer by name ("xu" = the solver's own copy used by gato_solve / gato_debug_stage):
  * "xu","D","Qq","Qd","Rd","q","r","c","Qqi","Qdi","Rdi","S","Pinv","gamma","lambda","dz","merit","merit_cur","rho","drho", "step".
  * Copies `count` floats to `out`; returns the buffer length in floats through *len when out == NULL.  "S" and "Pinv" are presented in
  * the reference's layout [k][row][left | main | right] (linalg.cuh:663-666) whatever the device's internal one is. */
-int gato_debug_read(GatoSolver* s, const char* name, float* out, uint64_t count, uint64_t* len);
-int gato_debug_write(GatoSolver* s, const char* name, const float* in, uint64_t count);
+int gato_debug_read(GatoSolver* s, const char* name, gato_real* out, uint64_t count, uint64_t* len);
+int gato_debug_write(GatoSolver* s, const char* name, const gato_real* in, uint64_t count);
 /* Runs ONE stage of an SQP iteration on device buffers previously filled (tests drive the stages one at a time):
  * stage: 0 merit(8 alphas) 1 kkt 2 schur(+stair) 3 pcg 4 dz 5 line-search 6 merit(1, dz ignored) 7 direct solve (instead of 3) */
-int gato_debug_stage(GatoSolver* s, int stage, float* xu, float timestep, const float* x_s, const float* ref, float* out);
+int gato_debug_stage(GatoSolver* s, int stage, gato_real* xu, gato_real timestep, const gato_real* x_s, const gato_real* ref, gato_real* out);
 
 /* Per-stage device time of the last gato_solve / gato_solve_device call when profiling was enabled (hipEvents around each
  * kernel family): out[7] = {merit, kkt, schur, pcg, dz, line_search, total} in microseconds, summed over the iterations. */

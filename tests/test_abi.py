@@ -35,6 +35,14 @@ def test_every_declared_symbol_is_exported(lib):
         assert hasattr(lib, n), "libgato_hip.so does not export %s" % n
     from gato_amd import _lib
     assert sorted(_lib.SYMBOLS) == names  # the ctypes binding covers exactly the header
+    # the float64 build (-DGATO_DOUBLE, the reference's USE_DOUBLES) exports the same entry points; gato_real is double there
+    f64 = C.CDLL(os.path.join(os.path.dirname(LIB), "libgato_hip_f64.so"))
+    for n in names:
+        assert hasattr(f64, n), "libgato_hip_f64.so does not export %s" % n
+    L = _lib.load(True)
+    p = L._PT()
+    L.gato_default_params(C.byref(p))
+    assert C.sizeof(p) == 15 * 8 and abs(p.pcg_tol - 1e-5) < 1e-12 and p.max_pcg_iters == 100   # doubles (and two padded uint32)
 
 
 def test_host_only_entry_points(lib):
@@ -85,9 +93,12 @@ def test_no_cpu_fallback():
 def test_missing_library_fails_loudly(monkeypatch):
     from gato_amd import _lib
     monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "_libs", {})
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libgato_hip.so")
-    with pytest.raises(_lib.GatoError, match="not built"):
-        _lib.load()
+    monkeypatch.setattr(_lib, "LIB_PATH_F64", "/nonexistent/libgato_hip_f64.so")
+    for f64 in (False, True):
+        with pytest.raises(_lib.GatoError, match="not built"):
+            _lib.load(f64)
 
 
 def test_cpp_wrapper_header_compiles(tmp_path):

@@ -22,7 +22,10 @@ def test_modules_and_classes_exist(plant, N):
     assert "set_as_reset_default: bool = True" in m.BSQP_1_float.set_rho_penalty_batch.__doc__        # py::arg(...) = true, bindings.cu:229-230
     from gato_amd import _gato_ext                                      # the classes are the COMPILED pybind11 class with (plant, N, B) fixed
     assert issubclass(m.BSQP_1_float, _gato_ext.BSQP) and type(_gato_ext.BSQP).__name__ == "pybind11_type"
-    assert not hasattr(m, "BSQP_0_float") and not hasattr(m, "BSQP_8_double")
+    assert not hasattr(m, "BSQP_0_float")
+    dbl = m.BSQP_8_double                                               # a USE_DOUBLES build's classes (bindings.cu:244-252), batch <= 128
+    assert dbl.BATCH_SIZE == 8 and dbl.__name__ == "BSQP_8_double" and not issubclass(dbl, _gato_ext.BSQP)
+    assert not hasattr(m, "BSQP_256_double")
 
 
 def test_facade_signature_and_errors():
