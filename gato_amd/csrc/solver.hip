@@ -272,7 +272,8 @@ template<class M> static void launch_kkt(GatoSolver* s, hipStream_t st, float dt
 }
 // ---- the PCG launch plan ------------------------------------------------------------------------------------------------
 // Register-resident kernels pcgc_kernel<M, RPT, MAXT, FOLD[, FUSE]>, tried in the order below; choice ids:
-//   4: <2 rows, 3 waves/SIMD>   6: <1 row>   5: <3 rows, 2 waves/SIMD>   2: <3 rows>   3: <2 rows>   1: <6 rows>   0: streaming pcg_kernel
+//   2: <3 rows>   3: <2 rows>   1: <6 rows>   0: streaming pcg_kernel   (round 1 also measured <2 rows, 3 waves/SIMD>, <1 row> and
+//   <3 rows, 512 threads>: 172 / 213 / 151 us per launch at C2, profiles/r01d_pcg_variants.txt -- removed)
 //   7: pcgs_kernel, symmetric half storage, 4 N threads (long horizons: the system stays on the CU where the others would stream it)
 // Measured at indy7 N=32 B=1024 (profiles/r01d_pcg_variants.txt): 3 rows/thread 151 us, 2 rows 172 us, 1 row 213 us, 6 rows (one wave
 // per trajectory) 217 us per launch.  3 rows per thread first: 256 registers without spills = two wavefronts per SIMD = four 2-wave
@@ -356,15 +357,12 @@ template<class M> static void launch_pcgs(GatoSolver* s, hipStream_t st, int sqp
 template<class M> static int plan_pcg(GatoSolver* s)
 {
     constexpr int NX = 2 * M::NQ;
-    const char* e = getenv("GATO_PCG_VARIANT");  // test / tuning override: 0 streaming, 1 RPT=6, 2 RPT=3, 3 RPT=2, 4..6 see above
+    const char* e = getenv("GATO_PCG_VARIANT");  // test / tuning override: 0 streaming, 1 RPT=6, 2 RPT=3, 3 RPT=2, 7 symmetric storage
     const int v = e ? atoi(e) : 100;
     const char* f = getenv("GATO_PCG_FOLD");
     const bool fold_wanted = !(f && atoi(f) == 0);
     int choice = 0;
-    if (v == 4 && pcgc_fits<M, 2, 3>(s)) choice = 4;
-    else if (v == 6 && pcgc_fits<M, 1>(s)) choice = 6;
-    else if (v == 5 && pcgc_fits<M, 3, 2>(s)) choice = 5;
-    else if ((v == 100 || v == 2) && pcgc_fits<M, 3>(s)) choice = 2;
+    if ((v == 100 || v == 2) && pcgc_fits<M, 3>(s)) choice = 2;
     else if ((v == 100 || v == 3) && pcgc_fits<M, 2>(s)) choice = 3;
     else if ((v == 100 || v == 1) && pcgc_fits<M, 6>(s)) choice = 1;
     // symmetric half storage: asked for (7), or the default where no full-storage kernel holds the system (iiwa14 N = 128)
@@ -377,9 +375,6 @@ template<class M> static int plan_pcg(GatoSolver* s)
     bool fold = fold_wanted && choice != 0 && (choice == 7 || pcg_vec_lds(s) + pcg_fold_lds(s) <= 150 * 1024);  // pcgs folds inside its own LDS
     if (fold) {
         switch (choice) {
-            case 4: fold = pcgc_grant_fold<M, 2, 3>(s); break;
-            case 6: fold = pcgc_grant_fold<M, 1>(s); break;
-            case 5: fold = pcgc_grant_fold<M, 3, 2>(s); break;
             case 2: fold = pcgc_grant_fold<M, 3>(s); break;
             case 3: fold = pcgc_grant_fold<M, 2>(s); break;
             case 1: fold = pcgc_grant_fold<M, 6>(s); break;
@@ -468,9 +463,6 @@ template<class M> static void launch_pcg(GatoSolver* s, hipStream_t st, int sqp_
     const int rows = s->N * s->nx;
     const size_t lds = pcg_vec_lds(s);
     switch (s->pcg_choice) {
-        case 4: launch_pcgc<M, 2, 3>(s, st, sqp_iter, write_p); return;
-        case 6: launch_pcgc<M, 1>(s, st, sqp_iter, write_p); return;
-        case 5: launch_pcgc<M, 3, 2>(s, st, sqp_iter, write_p); return;
         case 2: launch_pcgc<M, 3>(s, st, sqp_iter, write_p); return;
         case 3: launch_pcgc<M, 2>(s, st, sqp_iter, write_p); return;
         case 1: launch_pcgc<M, 6>(s, st, sqp_iter, write_p); return;
