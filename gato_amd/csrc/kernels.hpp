@@ -1425,7 +1425,7 @@ __global__ __launch_bounds__(MAXT) void pcg_kernel(Buffers bf, int N, int B, uin
 // Packed FP32: each row keeps an (even, odd) pair of partial sums and advances it with v_pk_fma_f32 -- two FMAs per issued
 // instruction; the matrix rows already sit in consecutive registers and the window arrives as 16-byte LDS reads, so no packing
 // moves are needed.  The pair is added once at the end.
-typedef real2 f32x2;   // a pair of reals: one v_pk_fma_f32 per fma in the fp32 build
+typedef float f32x2 __attribute__((ext_vector_type(2)));   // a pair of reals: one v_pk_fma_f32 per fma in the fp32 build
 // Association of a row's 3 nx products (every register-resident PCG form shares it, so that they give the same bits): the row is cut
 // into two halves of 3 nx / 2 columns; each half accumulates its even and its odd columns in sequence (one packed FMA chain), and
 // the row sum is (even_lo + even_hi) + (odd_lo + odd_hi) -- the pair form of pcgc_kernel gives one half to each lane of a pair.
