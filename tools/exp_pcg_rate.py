@@ -28,7 +28,8 @@ from gato_amd.bsqp.workloads import fig8_problem
 plant = os.environ.get("PLANT", "indy7")
 N = int(os.environ.get("KNOTS", "32"))
 rec = []
-for B, reps in ((1, 24), (16, 12), (1024, 3)):
+BATCHES = [tuple(int(v) for v in t.split(":")) for t in os.environ.get("BATCHES", "1:24,16:12,1024:3").split(",")]
+for B, reps in BATCHES:
     its = []
     s = NativeSolver(plant, N, B, dt=0.01, **dict(DEFAULT_SOLVER_PARAMS, max_sqp_iters=10))
     if os.environ.get("DIRECT"):
