@@ -558,16 +558,24 @@ template<class M, int g> GATO_DEV void kkt_dispatch(int task, const Buffers& bf,
 // lanes.  Written directly, every lane's 24-byte column pieces were separate 8-byte requests to different cache lines (54 per knot);
 // the request rate of those stores, not the arithmetic, bounded this kernel.
 template<class M>
-__global__ __launch_bounds__(64 * ((M::NQ + 1) / 2 + 1), 2) void kkt_kernel(Buffers bf, int N, int B, float dt, int sqp_iter, float thresh, int row0)
+__global__ __launch_bounds__(64 * ((M::NQ + 1) / 2 + 1), 2) void kkt_kernel(Buffers bf, int N, int B, float dt, int sqp_iter, float thresh, int row0,
+                                                                             real4* __restrict__ zero4, uint32_t zero_n4)
 {
     constexpr int NQ = M::NQ, NX = 2 * NQ, NU = NQ, KS = NX + NU, NT = (NQ + 1) / 2 + 1, ND = 3 * NQ * NQ;
     extern __shared__ __attribute__((aligned(16))) float ldsD[];
-    if (bf.ctrl->done) return;
-    if (sqp_iter > 0 && (float)bf.num_solved[sqp_iter - 1] >= thresh) {
-        // the previous iteration ended the loop (bsqp.cuh:165): raise `done` for everything that follows; whether a workgroup sees the
-        // flag or the count, it leaves
-        if (blockIdx.x == 0 && threadIdx.x == 0) bf.ctrl->done = 1;
-        return;
+    if (zero_n4) {
+        // the FIRST launch of a solve whose initial merit is formed by the first step launch (solver.hip:solve_impl): it clears what
+        // bsqp.cuh:112-114 memsets (dz, PCG counts, convergence flags) and the device-side loop control -- nothing in this kernel
+        // reads them at iteration 0, the next launch does -- so a solve needs neither a fill nor a merit launch ahead of its loop
+        for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < zero_n4; i += gridDim.x * blockDim.x) zero4[i] = make_real4(0.f, 0.f, 0.f, 0.f);
+    } else {
+        if (bf.ctrl->done) return;
+        if (sqp_iter > 0 && (float)bf.num_solved[sqp_iter - 1] >= thresh) {
+            // the previous iteration ended the loop (bsqp.cuh:165): raise `done` for everything that follows; whether a workgroup sees
+            // the flag or the count, it leaves
+            if (blockIdx.x == 0 && threadIdx.x == 0) bf.ctrl->done = 1;
+            return;
+        }
     }
     const int lane = threadIdx.x & 63;
     const int task = threadIdx.x >> 6;  // wave-uniform
@@ -2558,8 +2566,10 @@ __global__ __launch_bounds__(256) void dz_kernel(Buffers bf, int N, int B, float
 // =========================================================================================================================
 // the line search of trajectory b by its workgroup: mer = the 8 merits, dz = the step (global or LDS)
 // `drho_reset` (non-null in the LAST iteration of a solve): drho goes back to its default once the search has used it (bsqp.cuh:189)
+// cur_lds: the merit of the current iterate when the caller has just formed it (first step launch of a solve) instead of
+// bf.merit_cur[b], which thread 0 then initialises
 GATO_DEV void line_search_block(const Buffers& bf, int b, int B, int traj, const float* mer, const float* dz, int adapt_rho, int sqp_iter,
-                                const float* drho_reset)
+                                const float* drho_reset, const float* cur_lds = nullptr)
 {
     float best = 1e38f;
     uint32_t idx = 0;
@@ -2568,10 +2578,11 @@ GATO_DEV void line_search_block(const Buffers& bf, int b, int B, int traj, const
         const float m = mer[i];
         if (m < best) { best = m; idx = i; }  // first minimum: ties keep the larger alpha
     }
-    const float cur = bf.merit_cur[b];
+    const float cur = cur_lds ? *cur_lds : bf.merit_cur[b];
     const bool success = best < cur;
     __syncthreads();  // everyone has read merit_cur before thread 0 overwrites it
     if (threadIdx.x == 0) {
+        if (cur_lds) bf.merit_cur[b] = cur;
         if (adapt_rho) {
             const float dr = bf.drho[b];
             const float mult = success ? fminf(dr / RHO_FACTOR, 1 / RHO_FACTOR) : fmaxf(dr * RHO_FACTOR, RHO_FACTOR);
@@ -2622,38 +2633,50 @@ __global__ __launch_bounds__(128) void line_search_kernel(Buffers bf, int traj, 
 // merit over two wavefronts through LDS in the order of the stand-alone merit kernel.
 template<class M, int MAXT>
 __global__ __launch_bounds__(MAXT) void step_kernel(Buffers bf, int N, int B, float dt, int sqp_iter, float thresh, int adapt_rho,
-                                                    const float* __restrict__ drho_init, int last_iter)
+                                                    const float* __restrict__ drho_init, int last_iter, float* __restrict__ merit_init0)
 {
+    // merit_init0 != nullptr: the first step launch of a solve, (NUM_ALPHAS + 1) N lanes -- the extra N lanes form the merit of the
+    // CURRENT iterate (bsqp.cuh:116-118: the line search's reference value and the `initial_merit` statistic) with the code and the
+    // sum tree of merit_kernel<M, 1>, so a solve has no merit launch ahead of its loop
     constexpr int NQ = M::NQ, NX = 2 * NQ, NU = NQ, KS = NX + NU;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     if (bf.ctrl->done) return;
     const int b = blockIdx.x, t = threadIdx.x;
     const int traj = KS * N - NU;
     float* dzs = lds;
-    float* mer = lds + ((traj + 3) & ~3);
+    float* mer = lds + ((traj + 3) & ~3);   // NUM_ALPHAS merits, the current merit at [NUM_ALPHAS], wavefront partials from [12]
     if (b == 0 && t == 0) bf.ctrl->iters_done = sqp_iter + 1;
     const Costs cw = load_costs(bf, b);  // fetched now, used after the dz phase: the latency hides behind it
     if (t < N) dz_knot<M, 1>(bf, N, b, t, dt, dzs);              // state rows
     else if (t < 2 * N) dz_knot<M, 2>(bf, N, b, t - N, dt, dzs);  // control rows
+    const int k = t % N, ai = t / N;
     // The loop breaks before the line search (bsqp.cuh:165); every workgroup takes the same branch.  `done` is raised by the NEXT
     // launch (kkt_kernel): set here it could stop a workgroup of this very launch before its dz.
     if ((float)bf.num_solved[sqp_iter] >= thresh) {
+        if (merit_init0) {   // the solve ends in its first iteration: its initial (= final) merit is still owed
+            if (ai == NUM_ALPHAS) {
+                float m = merit_term<M>(bf, cw, N, b, k, 0.f, 0, dzs, dt);
+                m = seg_sum(m, N, mer + 12);
+                if (k == 0) { bf.merit_cur[b] = m; merit_init0[b] = m; }
+            }
+        }
         if (t == 0) bf.drho[b] = drho_init[b];  // the solve ends here (bsqp.cuh:165,189)
         return;
     }
     __syncthreads();
     {
-        const int k = t % N, ai = t / N;
-        const float alpha = (float)(1.0 / (double)(1 << ai));
-        float m = merit_term<M>(bf, cw, N, b, k, alpha, 1, dzs, dt);
-        m = seg_sum(m, N, mer + 8);  // N <= 64: inside one wavefront; N = 128: two wavefront partials per merit through LDS
+        const bool cand = ai < NUM_ALPHAS;
+        const float alpha = cand ? (float)(1.0 / (double)(1 << ai)) : 0.f;
+        float m = merit_term<M>(bf, cw, N, b, k, alpha, cand ? 1 : 0, dzs, dt);
+        m = seg_sum(m, N, mer + 12);  // N <= 64: inside one wavefront; N = 128: two wavefront partials per merit through LDS
         if (k == 0) {
             mer[ai] = m;
-            bf.merit[(size_t)b * NUM_ALPHAS + ai] = m;
+            if (cand) bf.merit[(size_t)b * NUM_ALPHAS + ai] = m;
+            else merit_init0[b] = m;
         }
     }
     __syncthreads();
-    line_search_block(bf, b, B, traj, mer, dzs, adapt_rho, sqp_iter, last_iter ? drho_init : nullptr);
+    line_search_block(bf, b, B, traj, mer, dzs, adapt_rho, sqp_iter, last_iter ? drho_init : nullptr, merit_init0 ? mer + NUM_ALPHAS : nullptr);
 }
 
 // =========================================================================================================================

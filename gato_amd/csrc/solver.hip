@@ -66,6 +66,8 @@ struct GatoSolver {
     // streaming pcg_kernel), whether it forms the stair off-diagonals itself (then schur2_kernel is not launched) and whether the
     // Schur complement is formed inside it.  Tuning overrides GATO_PCG_VARIANT / GATO_PCG_FOLD are read there, never in the solve loop.
     int pcg_choice, pcg_fold, pcg_fused, pcg_pair;
+    int cus;   // compute units of the solver's device
+    int merit_in_step_forced;   // GATO_MERIT_IN_STEP = 0 / 1, else -1
     int linear_solver;  // 0: PCG (the reference's solver, pcg.cuh), 1: direct block-tridiagonal sweep (gato_set_linear_solver)
     // optional hipGraph replay of the host-buffer solve (gato_set_graph_mode): the fixed launch sequence of one solve captured once per
     // (dt, iteration count, mode switches) on the solver's own stream -- the buffers of gato_solve are the solver's own, so the kernel
@@ -142,6 +144,7 @@ static int create_impl(GatoSolver* s, int plant, int N, int B, const GatoParams*
     s->graph_exec = nullptr;
     s->fuse_schur = getenv("GATO_SCHUR_FUSED") ? atoi(getenv("GATO_SCHUR_FUSED")) : 1;
     s->fuse_step = getenv("GATO_STEP_FUSED") ? atoi(getenv("GATO_STEP_FUSED")) : 1;
+    s->merit_in_step_forced = getenv("GATO_MERIT_IN_STEP") ? atoi(getenv("GATO_MERIT_IN_STEP")) : -1;
     s->schur_rowlane = getenv("GATO_SCHUR_ROWLANE") ? atoi(getenv("GATO_SCHUR_ROWLANE")) : (s->nq % 2);
     s->profiling = 0;
     s->last_stream = nullptr;
@@ -262,13 +265,14 @@ template<class M> static void launch_merit(GatoSolver* s, hipStream_t st, int na
         hipLaunchKernelGGL((merit_kernel<M, NUM_ALPHAS>), dim3(cdiv(n, 256)), dim3(256), 0, st, s->bf, s->N, s->B, dt, use_dz, sqp_iter,
                            thresh, out, (float*)nullptr, (real4*)nullptr, 0u);
 }
-template<class M> static void launch_kkt(GatoSolver* s, hipStream_t st, float dt, int sqp_iter, int row0 = 0)
+template<class M> static void launch_kkt(GatoSolver* s, hipStream_t st, float dt, int sqp_iter, int row0 = 0, bool clear_slab = false)
 {
     // The same task split for EVERY batch size: it changes the generated code (and with it the last bit of D), so choosing it by
     // batch size would make a trajectory's iterates depend on how many neighbours it has.
     constexpr int NT = (M::NQ + 1) / 2 + 1;
     hipLaunchKernelGGL((kkt_kernel<M>), dim3(cdiv((long)s->B * s->N, 64)), dim3(64 * NT), (size_t)64 * 3 * M::NQ * M::NQ * sizeof(float), st, s->bf, s->N,
-                       s->B, dt, sqp_iter, s->p.solve_ratio * (float)s->B, row0);
+                       s->B, dt, sqp_iter, s->p.solve_ratio * (float)s->B, row0, reinterpret_cast<real4*>(clear_slab ? s->zero_slab : nullptr),
+                       clear_slab ? (uint32_t)(s->zero_words / 4) : 0u);
 }
 // ---- the PCG launch plan ------------------------------------------------------------------------------------------------
 // Register-resident kernels pcgc_kernel<M, RPT, MAXT, FOLD[, FUSE]>, tried in the order below; choice ids:
@@ -356,6 +360,7 @@ template<class M> static void launch_pcgs(GatoSolver* s, hipStream_t st, int sqp
 
 template<class M> static int plan_pcg(GatoSolver* s)
 {
+    if (hipDeviceGetAttribute(&s->cus, hipDeviceAttributeMultiprocessorCount, s->device) != hipSuccess) s->cus = 0;
     constexpr int NX = 2 * M::NQ;
     const char* e = getenv("GATO_PCG_VARIANT");  // test / tuning override: 0 streaming, 1 RPT=6, 2 RPT=3, 3 RPT=2, 7 symmetric storage
     const int v = e ? atoi(e) : 100;
@@ -398,8 +403,7 @@ template<class M> static int plan_pcg(GatoSolver* s)
     bool pair = false;
     if constexpr (NX == 12) {
         const int T2 = 2 * PcgcShape<NX, 3, 0>::threads(s->N * s->nx);
-        int cus = 0;
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, s->device) != hipSuccess) cus = 0;
+        const int cus = s->cus;
         const char* pe = getenv("GATO_PCG_PAIR");
         const bool want = pe ? atoi(pe) != 0 : (long)s->B * (T2 / 64) <= (long)cus * 8;   // 2 wavefronts per SIMD at 236 registers
         pair = fused && want && T2 <= 256 && T2 >= 64 &&
@@ -501,16 +505,32 @@ static bool step_fused(const GatoSolver* s)
     return s->fuse_step && NUM_ALPHAS * s->N <= 1024;
 }
 // last: this is the final iteration of the solve -- the line search also puts drho back to its default (bsqp.cuh:189)
-template<class M> static void launch_step(GatoSolver* s, hipStream_t st, float dt, int sqp_iter, int last)
+// first: the first step launch of a solve also forms the merit of the current iterate ((NUM_ALPHAS + 1) N lanes; see merit_in_step)
+template<class M> static void launch_step(GatoSolver* s, hipStream_t st, float dt, int sqp_iter, int last, bool first = false)
 {
     const float thresh = (float)s->B * s->p.solve_ratio;
-    const size_t lds = (size_t)(((s->traj + 3) & ~3) + 8 + 16) * sizeof(float);   // the step, 8 merits, 16 wavefront partials
-    if (NUM_ALPHAS * s->N <= 512)
-        hipLaunchKernelGGL((step_kernel<M, 512>), dim3(s->B), dim3(NUM_ALPHAS * s->N), lds, st, s->bf, s->N, s->B, dt, sqp_iter, thresh,
-                           s->adapt_rho, (const float*)s->d_drho_init, last);
+    const size_t lds = (size_t)(((s->traj + 3) & ~3) + 12 + 16) * sizeof(float);   // the step, 8 + 1 merits, 16 wavefront partials
+    const int T = (NUM_ALPHAS + (first ? 1 : 0)) * s->N;
+    float* init0 = first ? s->d_merit_init0 : nullptr;
+    if (T <= 512)
+        hipLaunchKernelGGL((step_kernel<M, 512>), dim3(s->B), dim3(T), lds, st, s->bf, s->N, s->B, dt, sqp_iter, thresh, s->adapt_rho,
+                           (const float*)s->d_drho_init, last, init0);
     else
-        hipLaunchKernelGGL((step_kernel<M, 1024>), dim3(s->B), dim3(NUM_ALPHAS * s->N), lds, st, s->bf, s->N, s->B, dt, sqp_iter, thresh,
-                           s->adapt_rho, (const float*)s->d_drho_init, last);
+        hipLaunchKernelGGL((step_kernel<M, 1024>), dim3(s->B), dim3(T), lds, st, s->bf, s->N, s->B, dt, sqp_iter, thresh, s->adapt_rho,
+                           (const float*)s->d_drho_init, last, init0);
+}
+// The initial merit of a solve (bsqp.cuh:116-118) rides in the first step launch when that launch exists and has the lanes to spare:
+// no merit launch ahead of the loop (8-11 us per solve: 10 % of a one-iteration MPC solve at B = 1); the first assembly launch
+// clears the per-solve slab then.
+// Only while every workgroup of that launch is still resident at once (the step kernel runs 3-4 wavefronts per SIMD, >= 12 per CU,
+// tests/test_kernel_resources.py): at C2 the ninth N lanes push 1024 workgroups of 5 wavefronts past the chip (+10 us), while the
+// merit launch they replace costs 11 us of a 1.8 ms solve.  Either way the same device code forms the value: same bits.
+static bool merit_in_step(const GatoSolver* s, uint32_t iters)
+{
+    const int T = (NUM_ALPHAS + 1) * s->N;
+    if (!(iters > 0 && step_fused(s) && T <= 1024)) return false;
+    if (s->merit_in_step_forced >= 0) return s->merit_in_step_forced != 0;   // GATO_MERIT_IN_STEP
+    return (long)s->B * ((T + 63) / 64) <= (long)s->cus * 12;
 }
 static void launch_ls(GatoSolver* s, hipStream_t st, int sqp_iter, int last)
 {
@@ -542,16 +562,20 @@ template<class M> static int solve_impl(GatoSolver* s, float* d_xu, float dt, co
     s->last_stream_valid = true;
     size_t ei = 0;
     mark(s, st, -1, ei);
-    // bsqp.cuh:112-118 in ONE launch: the merit of the initial iterate (kept twice: running merit and merit_initial0) and the clearing of
-    // dz, pcg_iters, converged, ctrl, num_solved (the slab is a multiple of 64 words)
-    launch_merit<M>(s, st, 1, dt, 0, -1, bf.merit_cur, s->d_merit_init0, s->zero_slab, s->zero_words);
-    mark(s, st, ST_MERIT, ei);
     const uint32_t iters = s->p.max_sqp_iters <= s->max_iters_alloc ? s->p.max_sqp_iters : s->max_iters_alloc;
+    // bsqp.cuh:112-118: the merit of the initial iterate (kept twice: running merit and merit_initial0) and the clearing of dz,
+    // pcg_iters, converged, ctrl, num_solved (the slab is a multiple of 64 words) -- inside the first step / first assembly launch
+    // where the plan allows it, otherwise ONE launch ahead of the loop
+    const bool ride = merit_in_step(s, iters);
+    if (!ride) {
+        launch_merit<M>(s, st, 1, dt, 0, -1, bf.merit_cur, s->d_merit_init0, s->zero_slab, s->zero_words);
+        mark(s, st, ST_MERIT, ei);
+    }
     for (uint32_t it = 0; it < iters; it++) {
         const bool direct = s->linear_solver == 1;
         const bool fused = s->pcg_fused != 0 && !direct;
         const bool row0 = fused || s->schur_rowlane;   // the Q_0 rows by the assembly kernel's cost task (always, where the Schur kernel allows it)
-        launch_kkt<M>(s, st, dt, (int)it, row0 ? 1 : 0);
+        launch_kkt<M>(s, st, dt, (int)it, row0 ? 1 : 0, ride && it == 0);
         mark(s, st, ST_KKT, ei);
         if (direct) {
             launch_schur<M>(s, st, dt, false, true, row0);   // S and gamma only: no preconditioner in this mode
@@ -566,7 +590,7 @@ template<class M> static int solve_impl(GatoSolver* s, float* d_xu, float dt, co
         }
         mark(s, st, ST_PCG, ei);
         if (step_fused(s)) {
-            launch_step<M>(s, st, dt, (int)it, it + 1 == iters);
+            launch_step<M>(s, st, dt, (int)it, it + 1 == iters, ride && it == 0);
             mark(s, st, ST_MERIT, ei);
         } else {
             launch_dz<M>(s, st, dt, (int)it);
