@@ -394,6 +394,29 @@ def test_early_exit_on_device():
     assert np.all(r2["pcg_iters"] == 1) and r2["iters_done"] == 3
 
 
+@pytest.mark.parametrize("plant,N,B,kw", [("indy7", 32, 9, {}), ("indy7", 8, 3, {}), ("iiwa14", 64, 2, {}), ("iiwa14", 16, 5, {}),
+                                         ("indy7", 8, 2, {"solve_ratio": 0.0}), ("indy7", 16, 2, {"max_sqp_iters": 1})])
+def test_initial_merit_inside_the_first_step_launch(plant, N, B, kw, monkeypatch):
+    """solver.hip:merit_in_step -- the first step launch of a solve forms the merit of the current iterate in (NUM_ALPHAS + 1) N lanes
+    with merit_kernel's code and sum tree, and the first assembly launch clears the per-solve slab: forced on and off, every output of a
+    solve is the same bits, including a solve that ends at its first convergence check (solve_ratio = 0: the merit is still owed)."""
+    from gato_amd._lib import NativeSolver
+    p = dict(DEFAULT_SOLVER_PARAMS, max_sqp_iters=3)
+    p.update(kw)
+    pr = fig8_problem(plant, N, B, f_ext_std=1.0)
+    out = {}
+    for v in ("0", "1"):
+        monkeypatch.setenv("GATO_MERIT_IN_STEP", v)
+        s = NativeSolver(plant, N, B, dt=DT, **p)   # read when the solver is created
+        s.set_f_ext_batch(pr["f_ext"])
+        s.solve(pr["xu"], DT, pr["x_s"], pr["ref"])          # a first solve leaves state behind (lambda, rho, a dirty slab) ...
+        out[v] = s.solve(pr["xu"], DT, pr["x_s"], pr["ref"])  # ... the second one must not see it
+    monkeypatch.delenv("GATO_MERIT_IN_STEP")
+    for k in ("XU", "initial_merit", "final_merit", "ls_min_merit", "ls_step_size", "pcg_iters_all", "sqp_iters", "kkt_converged"):
+        np.testing.assert_array_equal(out["0"][k], out["1"][k], err_msg=k)
+    assert out["0"]["iters_done"] == out["1"]["iters_done"] and np.all(np.isfinite(out["1"]["initial_merit"])) and np.all(out["1"]["initial_merit"] > 0)
+
+
 @pytest.mark.parametrize("N,B,fstd", [(32, 24, 4.0), (64, 5, 0.0), (16, 7, 2.0), (4, 3, 1.0), (8, 2, 0.0)])
 def test_fused_kernels_equal_separate_launches(N, B, fstd, monkeypatch):
     """The fused launches (Schur complement inside the PCG kernel, dz + merit + line search in one step kernel) run the SAME device
