@@ -6,9 +6,11 @@
 //   * pcgc_kernel<.., FUSE>: one workgroup per trajectory, three rows of the block-tridiagonal system per thread.  The Schur
 //     complement is FORMED here by 4-lane groups (DPP pivot broadcast) and stays in registers together with the stair preconditioner
 //     for the whole PCG solve: S and P^-1 never reach global memory (the reference re-reads both on every PCG iteration,
-//     pcg.cuh:100,119); vectors are exchanged through LDS, dot products are DPP + one LDS slot per wavefront;
+//     pcg.cuh:100,119); vectors are exchanged through LDS, dot products are DPP + one LDS slot per wavefront; its PAIR form gives a
+//     row group to two lanes (half of the columns each, same bits) where the whole batch is resident that way; pcgs_kernel keeps
+//     long horizons (iiwa14 / indy7 N = 128) on the CU in symmetric half storage;
 //   * step_kernel: one workgroup per trajectory: dz -> merit at the 8 step sizes (lane = (alpha, knot), wave-butterfly sums:
-//     deterministic, no float atomics) -> line search -> xu, rho;
+//     deterministic, no float atomics) -> line search -> xu, rho; the first one of a solve also forms the initial merit;
 //   * stand-alone forms of every stage (schurq/schur1/schur2, pcg(c)_kernel, dz, merit<8>, line_search) serve the stage tests, iiwa14
 //     (nx = 14) and N > 64;
 //   * the SQP loop has no host round trip: convergence counting and the solve_ratio early exit run on the device (Ctrl).
@@ -22,6 +24,7 @@
 //   Qq   [b][k][nq^2], Qd [b][k][nq]   Q_k = blkdiag(Qq, diag(Qd))   (the cost Hessian has no other non-zeros, indy7_plant.cuh:375-408)
 //   Rd   [b][k][nu]                     R_k = diag(Rd)
 //   q [b][k][nx], r [b][k][nu], c [b][k][nx]; Qqi/Qdi/Rdi hold the inverses (separate buffers: no RAW hazard)
+// `float` is the solver's REAL type: real.hpp turns it into double for the float64 build (-DGATO_DOUBLE, the reference's USE_DOUBLES).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
