@@ -1611,7 +1611,9 @@ GATO_DEV float read_parts(const float* part)   // <= 4 wavefront partials
     return (a.x + a.y) + (a.z + a.w);
 }
 
-template<class M, int RPT, int MAXT, bool FOLD, bool FUSE = false, bool PAIR = false>
+// FULL: every thread owns a row group (threads x RPT == N nx: N a multiple of 16 in the fused forms) -- the masks of idle lanes and the
+// exec-mask juggling around the LDS stores drop out of the iteration (14 of ~305 instructions)
+template<class M, int RPT, int MAXT, bool FOLD, bool FUSE = false, bool PAIR = false, bool FULL = false>
 __global__ __launch_bounds__(MAXT) void pcgc_kernel(Buffers bf, int N, int B, uint32_t max_iters, int sqp_iter, int write_p, float dt)
 {
     constexpr int NQ = M::NQ, NX = 2 * NQ, BR = 3 * NX, BROW = 3 * NX * NX;
@@ -1638,7 +1640,7 @@ __global__ __launch_bounds__(MAXT) void pcgc_kernel(Buffers bf, int N, int B, ui
         // index in the single-lane form) and then split its 3 nx columns for the iteration
         const int tid = PAIR ? (int)(((threadIdx.x >> 3) << 2) | (threadIdx.x & 3)) : (int)threadIdx.x;
         const int r0 = tid * RPT;
-        const bool have = r0 < nrows;  // threads * RPT >= nrows; whole threads are in or out
+        const bool have = FULL || r0 < nrows;  // threads * RPT >= nrows; whole threads are in or out
         const int rr = have ? r0 : 0;
         const int kb = rr / NX;
         const float* gam = bf.gamma + (size_t)b * vecp;

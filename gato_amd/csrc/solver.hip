@@ -392,7 +392,8 @@ template<class M> static int plan_pcg(GatoSolver* s)
     bool fused = false;
     if constexpr (NX == 12) {
         fused = s->fuse_schur && fold && choice == 2 && PcgcShape<NX, 3, 0>::threads(s->N * s->nx) <= 256;
-        if (fused) fused = grant_lds(reinterpret_cast<const void*>(&pcgc_kernel<M, 3, 256, true, true>), pcg_fused_lds<M>(s));
+        if (fused) fused = grant_lds(reinterpret_cast<const void*>(&pcgc_kernel<M, 3, 256, true, true>), pcg_fused_lds<M>(s)) &&
+                           grant_lds(reinterpret_cast<const void*>(&pcgc_kernel<M, 3, 256, true, true, false, true>), pcg_fused_lds<M>(s));
     }
     s->pcg_fused = fused ? 1 : 0;
     // Pair form of the fused kernel: two lanes per row group (twice the threads, half of the columns each; same bits).  A PCG iteration
@@ -407,7 +408,8 @@ template<class M> static int plan_pcg(GatoSolver* s)
         const char* pe = getenv("GATO_PCG_PAIR");
         const bool want = pe ? atoi(pe) != 0 : (long)s->B * (T2 / 64) <= (long)cus * 8;   // 2 wavefronts per SIMD at 236 registers
         pair = fused && want && T2 <= 256 && T2 >= 64 &&
-               grant_lds(reinterpret_cast<const void*>(&pcgc_kernel<M, 3, 256, true, true, true>), pcg_fused_lds<M>(s));
+               grant_lds(reinterpret_cast<const void*>(&pcgc_kernel<M, 3, 256, true, true, true>), pcg_fused_lds<M>(s)) &&
+               grant_lds(reinterpret_cast<const void*>(&pcgc_kernel<M, 3, 256, true, true, true, true>), pcg_fused_lds<M>(s));
     }
     s->pcg_pair = pair ? 1 : 0;
     return GATO_OK;
@@ -453,12 +455,22 @@ template<class M> static void launch_pcg_fused(GatoSolver* s, hipStream_t st, fl
     constexpr int NX = 2 * M::NQ;
     if constexpr (NX == 12) {
         const int T = PcgcShape<NX, 3, 0>::threads(s->N * s->nx);
-        if (s->pcg_pair)
-            hipLaunchKernelGGL((pcgc_kernel<M, 3, 256, true, true, true>), dim3(s->B), dim3(2 * T), pcg_fused_lds<M>(s), st, s->bf, s->N, s->B,
-                               s->p.max_pcg_iters, sqp_iter, 0, dt);
-        else
-            hipLaunchKernelGGL((pcgc_kernel<M, 3, 256, true, true>), dim3(s->B), dim3(T), pcg_fused_lds<M>(s), st, s->bf, s->N, s->B,
-                               s->p.max_pcg_iters, sqp_iter, 0, dt);
+        const bool full = T * 3 == s->N * s->nx;   // every thread owns a row group (N a multiple of 16)
+        if (s->pcg_pair) {
+            if (full)
+                hipLaunchKernelGGL((pcgc_kernel<M, 3, 256, true, true, true, true>), dim3(s->B), dim3(2 * T), pcg_fused_lds<M>(s), st, s->bf, s->N, s->B,
+                                   s->p.max_pcg_iters, sqp_iter, 0, dt);
+            else
+                hipLaunchKernelGGL((pcgc_kernel<M, 3, 256, true, true, true>), dim3(s->B), dim3(2 * T), pcg_fused_lds<M>(s), st, s->bf, s->N, s->B,
+                                   s->p.max_pcg_iters, sqp_iter, 0, dt);
+        } else {
+            if (full)
+                hipLaunchKernelGGL((pcgc_kernel<M, 3, 256, true, true, false, true>), dim3(s->B), dim3(T), pcg_fused_lds<M>(s), st, s->bf, s->N, s->B,
+                                   s->p.max_pcg_iters, sqp_iter, 0, dt);
+            else
+                hipLaunchKernelGGL((pcgc_kernel<M, 3, 256, true, true>), dim3(s->B), dim3(T), pcg_fused_lds<M>(s), st, s->bf, s->N, s->B,
+                                   s->p.max_pcg_iters, sqp_iter, 0, dt);
+        }
     }
 }
 

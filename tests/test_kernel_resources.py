@@ -15,8 +15,8 @@ CSRC = os.path.join(ROOT, "gato_amd", "csrc")
 
 # kernel (regex on the mangled name) -> (max VGPRs, max AGPRs, max scratch bytes per lane)
 BUDGETS = {
-    r"pcgc_kernelINS_5Indy7ELi3ELi256ELb1ELb1ELb0E": (256, 0, 0),      # C2's PCG: fused Schur + fold, single-lane form
-    r"pcgc_kernelINS_5Indy7ELi3ELi256ELb1ELb1ELb1E": (256, 0, 0),      # pair form
+    r"pcgc_kernelINS_5Indy7ELi3ELi256ELb1ELb1ELb0ELb[01]E": (256, 0, 0),   # C2's PCG: fused Schur + fold, single-lane form (FULL or not)
+    r"pcgc_kernelINS_5Indy7ELi3ELi256ELb1ELb1ELb1ELb[01]E": (256, 0, 0),   # pair form
     r"pcgs_kernelINS_6Iiwa14ELi512ELb1E": (256, 0, 64),                 # C3's PCG (symmetric half storage, fold)
     r"pcgc_kernelINS_6Iiwa14ELi2ELi512ELb1ELb0ELb0E": (256, 0, 0),     # C5's PCG
     r"kkt_kernelINS_5Indy7E": (256, 0, 0),
