@@ -6,7 +6,7 @@ import sys
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "csrc", "libgato_hip.so")
+LIB_PATH = os.environ.get("GATO_HIP_LIB") or os.path.join(HERE, "csrc", "libgato_hip.so")   # GATO_HIP_LIB: an experimental build (tools/)
 LIB_PATH_F64 = os.path.join(HERE, "csrc", "libgato_hip_f64.so")   # the USE_DOUBLES build (gato/settings.h:7-11): same entry points on double
 PLANTS = {"indy7": 0, "iiwa14": 1}
 NQ = {"indy7": 6, "iiwa14": 7}
