@@ -1550,20 +1550,16 @@ template<int NXT, int RPT> GATO_DEV void rows_dot_parked(const float (*rows)[3 *
 // read back: S and P^-1 never exist in global memory, one launch and ~150 MB of traffic per iteration less.  Block row 0 (the
 // Q_0 rows) comes from the assembly kernel's cost task.
 // ---- helpers of the PAIR form of pcgc_kernel: a row group's 3 nx columns split over two lanes ----------------------------------
-// the partner lane's value: PM = 0 pairs are adjacent lanes (2g, 2g+1); PM = 1 pairs are lanes (t, t ^ 4) -- the two quads of an 8-lane
-// group (row_shl:4 into banks 0 and 2, row_shr:4 into banks 1 and 3)
-template<int PM> GATO_DEV float pair_partner(float p)
+// A pair is lanes (t, t ^ 4): the two quads of an 8-lane group run the same 4-lane Schur group through the prologue.
+// the partner lane's value: row_shl:4 into banks 0 and 2, row_shr:4 into banks 1 and 3
+GATO_DEV float pair_partner(float p)
 {
-    if constexpr (PM == 0) {
-        return dpp_get<0xB1>(p);
-    } else {
-        const float a = dpp_mov<0x104, 0xf, 0x5>((float)0, p);
-        return dpp_mov<0x114, 0xf, 0xA>(a, p);
-    }
+    const float a = dpp_mov<0x104, 0xf, 0x5>((float)0, p);
+    return dpp_mov<0x114, 0xf, 0xA>(a, p);
 }
-template<int HC, int RPT, int PM = 0> GATO_DEV void rows_dot_half(const float (*rows)[HC], const float* w, float* acc)
+// rows x (the lane's half window, in registers), joined with the partner's half in rows_dot's association
+template<int HC, int RPT> GATO_DEV void rows_dot_half(const float (*rows)[HC], const float* w, float* acc)
 {
-    // w: the lane's half window in registers
     static_assert(HC % 2 == 0, "whole pairs");
     f32x2 a2[RPT];
 #pragma unroll
@@ -1576,7 +1572,7 @@ template<int HC, int RPT, int PM = 0> GATO_DEV void rows_dot_half(const float (*
     }
 #pragma unroll
     for (int u = 0; u < RPT; u++) {
-        const f32x2 t = a2[u] + f32x2{pair_partner<PM>(a2[u].x), pair_partner<PM>(a2[u].y)};   // rows_dot's association
+        const f32x2 t = a2[u] + f32x2{pair_partner(a2[u].x), pair_partner(a2[u].y)};
         acc[u] = t.x + t.y;
     }
 }
@@ -1589,15 +1585,14 @@ template<int HC> GATO_DEV void load_half_window(float* w, const float* __restric
         w[2 * c + 1] = v.y;
     }
 }
-// sum over the wavefront of a value that both lanes of every pair hold, each pair counted once: the butterfly step that would add
-// a lane to its partner is left out (PM = 0: quad_perm [1,0,3,2]; PM = 1: row_half_mirror, which adds the two quads of an 8-lane group)
-template<int PM = 0> GATO_DEV float wave_sum_pairs(float v)
+// sum over the wavefront of a value that both lanes of every pair hold, each pair counted once: wave_sum without the butterfly that
+// would add a lane to its partner (row_half_mirror adds the two quads of an 8-lane group) -- the same tree over the same row groups
+GATO_DEV float wave_sum_pairs(float v)
 {
 #define GATO_DPP_ADD(ctrl) v += dpp_get<ctrl>(v)
-    if constexpr (PM == 1) GATO_DPP_ADD(0xB1);   // quad_perm [1,0,3,2]
-    GATO_DPP_ADD(0x4E);                           // quad_perm [2,3,0,1]
-    if constexpr (PM == 0) GATO_DPP_ADD(0x141);  // row_half_mirror
-    GATO_DPP_ADD(0x140);                          // row_mirror
+    GATO_DPP_ADD(0xB1);   // quad_perm [1,0,3,2]
+    GATO_DPP_ADD(0x4E);   // quad_perm [2,3,0,1]
+    GATO_DPP_ADD(0x140);  // row_mirror
 #undef GATO_DPP_ADD
     const float r0 = lane_read(v, 0);
     const float r1 = lane_read(v, 16);
@@ -1845,13 +1840,13 @@ __global__ __launch_bounds__(MAXT) void pcgc_kernel(Buffers bf, int N, int B, ui
             __syncthreads();
             float w[HC], acc[RPT];
             load_half_window<HC>(w, wa);
-            rows_dot_half<HC, RPT, 1>(Sh, w, acc);  // r = gamma - S x
+            rows_dot_half<HC, RPT>(Sh, w, acc);  // r = gamma - S x
 #pragma unroll
             for (int u = 0; u < RPT; u++) rv[u] = have ? gv[u] - acc[u] : 0.f;
             if (owner) store_vec<RPT, RPT>(ob, rv);
             __syncthreads();
             load_half_window<HC>(w, wb);
-            rows_dot_half<HC, RPT, 1>(Ph, w, acc);  // z = p = P^-1 r
+            rows_dot_half<HC, RPT>(Ph, w, acc);  // z = p = P^-1 r
             float loc = 0.f;
 #pragma unroll
             for (int u = 0; u < RPT; u++) {
@@ -1859,7 +1854,7 @@ __global__ __launch_bounds__(MAXT) void pcgc_kernel(Buffers bf, int N, int B, ui
                 pv[u] = zv[u];
                 loc += rv[u] * zv[u];
             }
-            loc = wave_sum_pairs<1>(loc);
+            loc = wave_sum_pairs(loc);
             if (lead) partA[wv] = loc;
             __syncthreads();
             float rho = read_parts(partA);
@@ -1870,14 +1865,14 @@ __global__ __launch_bounds__(MAXT) void pcgc_kernel(Buffers bf, int N, int B, ui
                     if (owner) store_vec<RPT, RPT>(oa, pv);
                     __syncthreads();
                     load_half_window<HC>(w, wa);
-                    rows_dot_half<HC, RPT, 1>(Sh, w, acc);  // A p
+                    rows_dot_half<HC, RPT>(Sh, w, acc);  // A p
                     loc = 0.f;
 #pragma unroll
                     for (int u = 0; u < RPT; u++) {
                         if (!have) acc[u] = 0.f;
                         loc += pv[u] * acc[u];
                     }
-                    loc = wave_sum_pairs<1>(loc);
+                    loc = wave_sum_pairs(loc);
                     if (lead) partB[wv] = loc;
                     __syncthreads();
                     const float pAp = read_parts(partB);
@@ -1890,14 +1885,14 @@ __global__ __launch_bounds__(MAXT) void pcgc_kernel(Buffers bf, int N, int B, ui
                     if (owner) store_vec<RPT, RPT>(ob, rv);
                     __syncthreads();
                     load_half_window<HC>(w, wb);
-                    rows_dot_half<HC, RPT, 1>(Ph, w, acc);  // z = P^-1 r
+                    rows_dot_half<HC, RPT>(Ph, w, acc);  // z = P^-1 r
                     loc = 0.f;
 #pragma unroll
                     for (int u = 0; u < RPT; u++) {
                         zv[u] = have ? acc[u] : 0.f;
                         loc += rv[u] * zv[u];
                     }
-                    loc = wave_sum_pairs<1>(loc);
+                    loc = wave_sum_pairs(loc);
                     if (lead) partA[wv] = loc;
                     __syncthreads();
                     const float rho_new = read_parts(partA);
