@@ -317,7 +317,8 @@ template<class M, int RPT, int FORCE_WPS = 0> static bool pcgc_grant_fold(const 
         return false;
     } else {
         using Sh = PcgcShape<NX, RPT, FORCE_WPS>;
-        return grant_lds(reinterpret_cast<const void*>(&pcgc_kernel<M, RPT, Sh::MAXT, true>), pcg_vec_lds(s) + pcg_fold_lds(s));
+        return grant_lds(reinterpret_cast<const void*>(&pcgc_kernel<M, RPT, Sh::MAXT, true>), pcg_vec_lds(s) + pcg_fold_lds(s)) &&
+               grant_lds(reinterpret_cast<const void*>(&pcgc_kernel<M, RPT, Sh::MAXT, true, false, false, true>), pcg_vec_lds(s) + pcg_fold_lds(s));
     }
 }
 template<class M> static size_t pcg_fused_lds(const GatoSolver* s)
@@ -441,7 +442,11 @@ template<class M, int RPT, int FORCE_WPS = 0> static void launch_pcgc(GatoSolver
     if constexpr (NX % RPT == 0) {
         using Sh = PcgcShape<NX, RPT, FORCE_WPS>;
         const int T = Sh::threads(s->N * s->nx);
-        if (s->pcg_fold)
+        const bool full = T * RPT == s->N * s->nx;   // every thread owns rows: the mask-free form of the fold kernel (the solve path)
+        if (s->pcg_fold && full)
+            hipLaunchKernelGGL((pcgc_kernel<M, RPT, Sh::MAXT, true, false, false, true>), dim3(s->B), dim3(T), pcg_vec_lds(s) + pcg_fold_lds(s), st,
+                               s->bf, s->N, s->B, s->p.max_pcg_iters, sqp_iter, write_p, 0.f);
+        else if (s->pcg_fold)
             hipLaunchKernelGGL((pcgc_kernel<M, RPT, Sh::MAXT, true>), dim3(s->B), dim3(T), pcg_vec_lds(s) + pcg_fold_lds(s), st, s->bf, s->N, s->B,
                                s->p.max_pcg_iters, sqp_iter, write_p, 0.f);
         else
