@@ -67,6 +67,8 @@ struct Buffers {
     float *D, *Qq, *Qd, *Rd, *q, *r, *c, *Qqi, *Qdi, *Rdi, *S, *Pinv, *gamma, *dz;
     float *merit, *merit_cur, *step;
     int32_t* converged; uint32_t* pcg_iters;
+    const int32_t* order;  // a permutation of the trajectories: workgroup i of pcgc_kernel solves order[i] (identity unless the launch runs in
+                           // several rounds, then hardest-first by the previous iteration's PCG counts: order_by_pcg_iters)
     // per-iteration stats [max_iters][B]
     int32_t* st_pcg_iters; float *st_min_merit, *st_step;
     Ctrl* ctrl;
@@ -1618,7 +1620,7 @@ __global__ __launch_bounds__(MAXT) void pcgc_kernel(Buffers bf, int N, int B, ui
     static_assert(NX % RPT == 0, "rows of one thread must share a block row");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     if (bf.ctrl->done) return;
-    const int b = blockIdx.x;
+    const int b = bf.order[blockIdx.x];   // hardest-first where the launch runs in rounds (solver.hip: pcg_rounds), else the identity
     const int nrows = N * NX, vecp = (N + 2) * NX;
     float* va = lds;
     float* vb = lds + vecp;
@@ -2631,6 +2633,29 @@ __global__ __launch_bounds__(128) void line_search_kernel(Buffers bf, int traj, 
 // lane t is (alpha index t / N, knot t % N) of the merit evaluation, then all lanes apply the chosen step.
 // MAXT = 512 serves N <= 64 (the 8 merits of a trajectory are wave-level sums); MAXT = 1024 (N = 128: 128 registers per lane) sums a
 // merit over two wavefronts through LDS in the order of the stand-alone merit kernel.
+// One workgroup: order[] <- the trajectories sorted by this iteration's PCG iteration count, largest first (counting sort over 256 bins;
+// ties in the arrival order of the atomics -- any order is a valid schedule, the results do not depend on it).  Where a PCG launch
+// cannot hold every trajectory at once (iiwa14 N = 64, B = 512: one 7-wavefront workgroup per CU, two rounds) the long-running
+// trajectories -- the same ones from iteration to iteration -- start first instead of waiting for a slot.
+GATO_DEV void order_by_pcg_iters(const Buffers& bf, int B, int* scratch /* 512 ints of LDS */)
+{
+    int* hist = scratch;
+    int* off = scratch + 256;
+    int* order = const_cast<int*>(bf.order);
+    const int t = threadIdx.x, T = blockDim.x;
+    for (int i = t; i < 256; i += T) hist[i] = 0;
+    __syncthreads();
+    for (int i = t; i < B; i += T) atomicAdd(&hist[255 - min((int)bf.pcg_iters[i], 255)], 1);
+    __syncthreads();
+    for (int i = t; i < 256; i += T) {
+        int sum = 0;
+        for (int j = 0; j < i; j++) sum += hist[j];
+        off[i] = sum;
+    }
+    __syncthreads();
+    for (int i = t; i < B; i += T) order[atomicAdd(&off[255 - min((int)bf.pcg_iters[i], 255)], 1)] = i;
+}
+
 template<class M, int MAXT>
 __global__ __launch_bounds__(MAXT) void step_kernel(Buffers bf, int N, int B, float dt, int sqp_iter, float thresh, int adapt_rho,
                                                     const float* __restrict__ drho_init, int last_iter, float* __restrict__ merit_init0)
@@ -2642,6 +2667,10 @@ __global__ __launch_bounds__(MAXT) void step_kernel(Buffers bf, int N, int B, fl
     extern __shared__ __attribute__((aligned(16))) float lds[];
     if (bf.ctrl->done) return;
     const int b = blockIdx.x, t = threadIdx.x;
+    if (b == B) {   // one workgroup more than trajectories: the PCG launch plan runs in rounds and wants them hardest-first next time
+        order_by_pcg_iters(bf, B, reinterpret_cast<int*>(lds));
+        return;
+    }
     const int traj = KS * N - NU;
     float* dzs = lds;
     float* mer = lds + ((traj + 3) & ~3);   // NUM_ALPHAS merits, the current merit at [NUM_ALPHAS], wavefront partials from [12]

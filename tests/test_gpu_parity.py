@@ -394,6 +394,28 @@ def test_early_exit_on_device():
     assert np.all(r2["pcg_iters"] == 1) and r2["iters_done"] == 3
 
 
+@pytest.mark.parametrize("plant,N,B", [("indy7", 32, 700), ("iiwa14", 64, 300), ("indy7", 16, 40)])
+def test_hardest_first_schedule_changes_no_result(plant, N, B, monkeypatch):
+    """solver.hip:plan_pcg -- where a CU hosts several trajectories the PCG workgroups are dealt hardest-first (a permutation kept by one
+    extra workgroup of the step launch from the previous iteration's counts).  It is a schedule: forced on and off, whole solves are the
+    same bits."""
+    from gato_amd._lib import NativeSolver
+    p = dict(DEFAULT_SOLVER_PARAMS, max_sqp_iters=4)
+    pr = fig8_problem(plant, N, B, f_ext_std=1.0)
+    out = {}
+    for v in ("0", "1"):
+        monkeypatch.setenv("GATO_PCG_ORDER", v)
+        s = NativeSolver(plant, N, B, dt=DT, **p)   # read when the solver is created
+        s.set_f_ext_batch(pr["f_ext"])
+        out[v] = s.solve(pr["xu"], DT, pr["x_s"], pr["ref"])
+        out[v + "b"] = s.solve(out[v]["XU"], DT, pr["x_s"], pr["ref"])   # a second solve starts from the order the first one left
+    monkeypatch.delenv("GATO_PCG_ORDER")
+    for a, b in (("0", "1"), ("0b", "1b")):
+        for k in ("XU", "final_merit", "ls_step_size", "pcg_iters_all", "sqp_iters"):
+            np.testing.assert_array_equal(out[a][k], out[b][k], err_msg=k)
+    assert len(set(out["1"]["pcg_iters_all"][-1].tolist())) > 3   # the counts differ, so the order is not the identity
+
+
 @pytest.mark.parametrize("plant,N,B,kw", [("indy7", 32, 9, {}), ("indy7", 8, 3, {}), ("iiwa14", 64, 2, {}), ("iiwa14", 16, 5, {}),
                                          ("indy7", 8, 2, {"solve_ratio": 0.0}), ("indy7", 16, 2, {"max_sqp_iters": 1})])
 def test_initial_merit_inside_the_first_step_launch(plant, N, B, kw, monkeypatch):
