@@ -19,14 +19,17 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, N, B, q):
+def _worker(rank, world, port, N, B, q, one_device=False):
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    torch.cuda.set_device(rank)
-    dev = torch.device("cuda", rank)
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    torch.cuda.set_device(0 if one_device else rank)
+    dev = torch.device("cuda", 0 if one_device else rank)
+    if one_device:   # two ranks sharing the box's only GPU: RCCL refuses duplicate devices, gloo stages the collective through the host
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    else:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     from gato_amd._lib import NativeSolver
     from gato_amd.bsqp.config import DEFAULT_SOLVER_PARAMS
     from gato_amd.bsqp.workloads import fig8_problem
@@ -42,8 +45,15 @@ def _worker(rank, world, port, N, B, q):
     st = torch.cuda.current_stream().cuda_stream
     s.solve_device(pk.xu.data_ptr(), 0.01, xs.data_ptr(), ref.data_ptr(), st)
     s.copy_final_merit_device(pk.merit.data_ptr(), st)
-    pk.all_gather()
-    torch.cuda.synchronize()
+    if one_device:
+        torch.cuda.synchronize()
+        host = PackedResults(hi - lo, s.traj, world, "cpu")   # the same packed layout, gathered by the same single collective
+        host.local.copy_(pk.local.cpu())
+        host.all_gather()
+        pk = host
+    else:
+        pk.all_gather()
+        torch.cuda.synchronize()
     if rank == 0:
         q.put((pk.global_xu().cpu().numpy(), pk.global_merit().cpu().numpy(), pk.best()))
     dist.barrier()
@@ -58,6 +68,33 @@ def test_two_gpu_sharded_solve_equals_single_gpu():
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, N, B, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    xu, merit, best = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    from gato_amd._lib import NativeSolver
+    from gato_amd.bsqp.config import DEFAULT_SOLVER_PARAMS
+    from gato_amd.bsqp.workloads import fig8_problem
+    pr = fig8_problem("indy7", N, B)
+    one = NativeSolver("indy7", N, B, dt=0.01, **dict(DEFAULT_SOLVER_PARAMS, max_sqp_iters=3))
+    ref = one.solve(pr["xu"], 0.01, pr["x_s"], pr["ref"])
+    np.testing.assert_array_equal(xu, ref["XU"])
+    np.testing.assert_array_equal(merit, ref["final_merit"])
+    assert best[1] == int(np.argmin(ref["final_merit"]))
+
+
+def test_two_ranks_on_one_gpu_sharded_solve_equals_single_batch():
+    """The sharded PRODUCT path on the 1-GPU box: two processes, each with its own NativeSolver on cuda:0 solving its half of the batch
+    (per-rank lambda / rho / order state, problem rows by batch_offset), the packed one-collective gather (gloo, staged through the host:
+    RCCL will not take two ranks on one device) -- equals the single-process solve of the whole batch bit for bit."""
+    import torch.multiprocessing as mp
+    N, B, world = 32, 48, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, N, B, q, True)) for r in range(world)]
     for p in procs:
         p.start()
     xu, merit, best = q.get(timeout=300)
