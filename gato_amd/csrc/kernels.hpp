@@ -2657,7 +2657,7 @@ GATO_DEV void order_by_pcg_iters(const Buffers& bf, int B, int* scratch /* 512 i
 }
 
 template<class M, int MAXT>
-__global__ __launch_bounds__(MAXT) void step_kernel(Buffers bf, int N, int B, float dt, int sqp_iter, float thresh, int adapt_rho,
+__global__ __launch_bounds__(MAXT, MAXT == 512 ? 4 : 1) void step_kernel(Buffers bf, int N, int B, float dt, int sqp_iter, float thresh, int adapt_rho,
                                                     const float* __restrict__ drho_init, int last_iter, float* __restrict__ merit_init0)
 {
     // merit_init0 != nullptr: the first step launch of a solve, (NUM_ALPHAS + 1) N lanes -- the extra N lanes form the merit of the
