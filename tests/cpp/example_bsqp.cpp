@@ -9,7 +9,11 @@
 
 #include "bsqp.hpp"
 
+#ifdef GATO_DOUBLE
+typedef double T;   // the reference's USE_DOUBLES build: link with -lgato_hip_f64
+#else
 typedef float T;
+#endif
 #define CHECK(x)                                                                   \
     do {                                                                           \
         hipError_t e_ = (x);                                                       \
@@ -71,7 +75,7 @@ int main(int argc, char** argv)
     CHECK(hipDeviceSynchronize());
     CHECK(hipMemcpy(h_next.data(), d_xkp1, h_next.size() * sizeof(T), hipMemcpyDeviceToHost));
 
-    std::printf("XU Traj: %.6f, %.6f, %.6f, %.6f\n", h_xu[0], h_xu[1], h_xu[2], h_xu[3]);
+    std::printf("XU Traj: %.6f, %.6f, %.6f, %.6f\n", (double)h_xu[0], (double)h_xu[1], (double)h_xu[2], (double)h_xu[3]);
     std::printf("solve_time_us %.1f sqp_iterations %d line_searches %zu pcg_records %zu\n", stats.solve_time_us, stats.sqp_iterations[0],
                 stats.line_search_stats.size(), stats.pcg_stats.size());
     if (argc > 1) {
