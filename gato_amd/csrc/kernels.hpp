@@ -36,6 +36,8 @@
 
 namespace gato {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));   // a pair of reals: one v_pk_fma_f32 per fma in the fp32 build
+
 constexpr int NUM_ALPHAS = 8;        // settings.h:16
 constexpr float RHO_FACTOR = 1.2f;   // settings.h:20
 constexpr float RHO_MIN = 1e-8f;     // settings.h:21
@@ -722,21 +724,40 @@ template<int LPP, int RW, int NX, int P> GATO_DEV void gj_coop_step(float (*W)[N
 #pragma unroll
     for (int i = 0; i < RW; i++) {
         const float f = W[i][P] * pvInv;  // colv[r] * pvInv
+        // columns in pairs: away from the pivot column the update x - f prow[c] is one packed FMA for two columns (the same fma each)
 #pragma unroll
-        for (int c = 0; c < NX; c++) {
-            float x, yv;
-            if (c == P) {
-                yv = 0.f - f;  // x = 0, rowv = 1
-                x = 1.0f;
+        for (int c0 = 0; c0 < NX; c0 += 2) {
+            float xv[2], yv[2];
+            if (NX % 2 == 0 && c0 != (P & ~1)) {
+                const f32x2 x2 = {W[i][c0], W[i][c0 + 1]};
+                const f32x2 y2 = __builtin_elementwise_fma(f32x2{-f, -f}, f32x2{prow[c0], prow[c0 + 1]}, x2);
+                xv[0] = x2.x; xv[1] = x2.y;
+                yv[0] = y2.x; yv[1] = y2.y;
             } else {
-                x = W[i][c];
-                yv = x - f * prow[c];
+#pragma unroll
+                for (int e = 0; e < 2; e++) {
+                    const int c = c0 + e;
+                    if (c >= NX) break;
+                    if (c == P) {
+                        yv[e] = 0.f - f;  // x = 0, rowv = 1
+                        xv[e] = 1.0f;
+                    } else {
+                        xv[e] = W[i][c];
+                        yv[e] = xv[e] - f * prow[c];
+                    }
+                }
             }
-            if (i == I) {
-                const float piv = x * pvInv;  // the pivot row itself (only in the owner lane)
-                yv = owner ? piv : yv;
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                const int c = c0 + e;
+                if (c >= NX) break;
+                float y = yv[e];
+                if (i == I) {
+                    const float piv = xv[e] * pvInv;  // the pivot row itself (only in the owner lane)
+                    y = owner ? piv : y;
+                }
+                W[i][c] = y;
             }
-            W[i][c] = yv;
         }
     }
     if constexpr (P + 1 < NX) gj_coop_step<LPP, RW, NX, P + 1>(W, l, rho_unused);
@@ -1438,7 +1459,6 @@ __global__ __launch_bounds__(MAXT) void pcg_kernel(Buffers bf, int N, int B, uin
 // Packed FP32: each row keeps an (even, odd) pair of partial sums and advances it with v_pk_fma_f32 -- two FMAs per issued
 // instruction; the matrix rows already sit in consecutive registers and the window arrives as 16-byte LDS reads, so no packing
 // moves are needed.  The pair is added once at the end.
-typedef float f32x2 __attribute__((ext_vector_type(2)));   // a pair of reals: one v_pk_fma_f32 per fma in the fp32 build
 // Association of a row's 3 nx products (every register-resident PCG form shares it, so that they give the same bits): the row is cut
 // into two halves of 3 nx / 2 columns; each half accumulates its even and its odd columns in sequence (one packed FMA chain), and
 // the row sum is (even_lo + even_hi) + (odd_lo + odd_hi) -- the pair form of pcgc_kernel gives one half to each lane of a pair.
@@ -1608,6 +1628,29 @@ GATO_DEV float read_parts(const float* part)   // <= 4 wavefront partials
     return (a.x + a.y) + (a.z + a.w);
 }
 
+// acc[u][x] += a[u] * row[x] for the thread's RPT rows, as packed FMAs over column pairs (each element still sees exactly one fma per
+// term, in the same order: the bits of the scalar loop at half the instructions)
+template<int RPT, int NXT> GATO_DEV void rows_axpy(float (*acc)[NXT], const float* a, const float* __restrict__ row)
+{
+    if constexpr (NXT % 2 == 0) {
+#pragma unroll
+        for (int x = 0; x < NXT; x += 2) {
+            const f32x2 r2 = {row[x], row[x + 1]};
+#pragma unroll
+            for (int u = 0; u < RPT; u++) {
+                const f32x2 t = __builtin_elementwise_fma(f32x2{a[u], a[u]}, r2, f32x2{acc[u][x], acc[u][x + 1]});
+                acc[u][x] = t.x;
+                acc[u][x + 1] = t.y;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < RPT; u++)
+#pragma unroll
+            for (int x = 0; x < NXT; x++) acc[u][x] += a[u] * row[x];
+    }
+}
+
 // FULL: every thread owns a row group (threads x RPT == N nx: N a multiple of 16 in the fused forms) -- the masks of idle lanes and the
 // exec-mask juggling around the LDS stores drop out of the iteration (14 of ~305 instructions)
 template<class M, int RPT, int MAXT, bool FOLD, bool FUSE = false, bool PAIR = false, bool FULL = false>
@@ -1740,10 +1783,10 @@ __global__ __launch_bounds__(MAXT) void pcgc_kernel(Buffers bf, int N, int B, ui
                 for (int jj = 0; jj < NX; jj++) {
                     float prow_[NX];
                     load_vec<NX, LA>(prow_, Pm1 + jj * NX);
+                    float a_[RPT];
 #pragma unroll
-                    for (int u = 0; u < RPT; u++)
-#pragma unroll
-                        for (int x = 0; x < NX; x++) scr[u][x] += Srow[u][jj] * prow_[x];
+                    for (int u = 0; u < RPT; u++) a_[u] = Srow[u][jj];
+                    rows_axpy<RPT, NX>(scr, a_, prow_);
                 }
 #pragma unroll
                 for (int u = 0; u < RPT; u++) store_vec<NX, LA>(bufB + (kb * NX + i0 + u) * NX, scr[u]);
@@ -1761,10 +1804,10 @@ __global__ __launch_bounds__(MAXT) void pcgc_kernel(Buffers bf, int N, int B, ui
                     for (int jj = 0; jj < NX; jj++) {
                         float srow_[NX];
                         load_vec<NX, LA>(srow_, sc + jj * NX);
+                        float a_[RPT];
 #pragma unroll
-                        for (int u = 0; u < RPT; u++)
-#pragma unroll
-                            for (int x = 0; x < NX; x++) res[u][x] += Prow[u][NX + jj] * srow_[x];
+                        for (int u = 0; u < RPT; u++) a_[u] = Prow[u][NX + jj];
+                        rows_axpy<RPT, NX>(res, a_, srow_);
                     }
 #pragma unroll
                     for (int u = 0; u < RPT; u++)
