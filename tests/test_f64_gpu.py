@@ -92,3 +92,40 @@ def test_double_classes_of_the_modules():
     f.set_f_ext_batch(pr["f_ext"])
     rf = f.solve(pr["xu"], DT, pr["x_s"], pr["ref"])
     assert rf["XU"].dtype == np.float32 and np.median(np.abs(rf["XU"] - r["XU"])) < 1e-3
+
+
+def test_random_configurations_in_double():
+    """The randomised sweep of tools/fuzz_parity.py where it is crisp: both implementations in double.  Plant, horizon, batch, time step,
+    wrench, all seven cost weights (barrier terms included), rho and mu at random; two free iterations with PCG at its floor: same steps,
+    iteration counts within one, iterates to 1e-8 (1e-4 where the PCG needs more than 200 iterations even in double) -- no tolerance to hide an algebra error in a rarely taken branch."""
+    from gato_amd._lib import NativeSolver
+    from oracle.oracle import OracleSolver
+    rng = np.random.default_rng(11)
+    worst = 0.0
+    for case in range(24):
+        plant = str(rng.choice(["indy7", "iiwa14"]))
+        N = int(rng.choice([4, 8, 16, 32, 64]))
+        B = int(rng.integers(1, 6))
+        dt = float(rng.choice([0.005, 0.01, 0.02]))
+        p = dict(DEFAULT_SOLVER_PARAMS, max_sqp_iters=2, pcg_tol=1e-10, max_pcg_iters=2000, rho=float(10 ** rng.uniform(-3, -1)),
+                 mu=float(rng.choice([1.0, 10.0, 50.0])), q_cost=float(rng.choice([0.5, 2.0, 10.0])), qd_cost=float(10 ** rng.uniform(-4, -1)),
+                 u_cost=float(10 ** rng.uniform(-7, -5)), N_cost=float(rng.choice([10.0, 50.0, 100.0])), q_lim_cost=float(rng.choice([0.0, 0.01])),
+                 vel_lim_cost=float(rng.choice([0.0, 1e-3])), ctrl_lim_cost=float(rng.choice([0.0, 1e-4])))
+        pr = fig8_problem(plant, N, B, seed=int(rng.integers(0, 1000)), dt=0.01, f_ext_std=float(rng.choice([0.0, 3.0])))
+        nat = NativeSolver(plant, N, B, f64=True, dt=dt, **p)
+        o64 = OracleSolver(plant, N, B, dt=dt, f64=True, **p)
+        for s in (nat, o64):
+            s.set_f_ext_batch(pr["f_ext"])
+        rg = nat.solve(pr["xu"], dt, pr["x_s"], pr["ref"])
+        ro = o64.solve(pr["xu"], dt, pr["x_s"], pr["ref"])
+        tag = (case, plant, N, B, dt, p)
+        np.testing.assert_array_equal(rg["ls_step_size"], ro["ls_step_size"], err_msg=str(tag))
+        assert np.abs(rg["pcg_iters"] - ro["pcg_iters"]).max() <= 1, tag   # an exit test crossed one iteration apart, at several hundred
+        e = float(np.abs(rg["XU"] - ro["XU"]).max() / np.abs(ro["XU"]).max())
+        worst = max(worst, e)
+        # a PCG that needs several hundred iterations in double sits on cond(S) ~ 1e10: its solution carries 1e-10 x cond of rounding
+        hard = int(ro["pcg_iters"].max()) > 200
+        assert e <= (1e-4 if hard else 1e-8), (tag, e)
+        if not hard:   # (the merit multiplies a 1e-5 iterate difference by mu |d defect / d x|: not a measure there)
+            assert np.abs(rg["final_merit"] - ro["final_merit"]).max() <= 1e-8 * np.abs(ro["final_merit"]).max(), tag
+    assert worst > 0.0   # two implementations, not one compared with itself
