@@ -999,10 +999,17 @@ __global__ __launch_bounds__(256) void schur1_kernel(Buffers bf, int N, int B, f
 {
     constexpr int NQ = M::NQ, NX = 2 * NQ, NU = NQ, BLK = NX * NX, BROW = 3 * NX * NX, ND = 3 * NQ * NQ, NQQ = NQ * NQ;
     static_assert(NX <= 16, "one group of 16 lanes per knot");
-    // record of one knot: D | Qi | di | ri | q | r | Qi1 | di1 | q1 | c1   (Qi1 .. c1: knot k+1)
-    constexpr int O_QI = ND, O_DI = O_QI + NQQ, O_RI = O_DI + NQ, O_Q = O_RI + NU, O_R = O_Q + NX, O_QI1 = O_R + NU, O_DI1 = O_QI1 + NQQ,
-                  O_Q1 = O_DI1 + NQ, O_C1 = O_Q1 + NX, REC = O_C1 + NX + 1;   // + 1: odd stride, the 16 records of a workgroup spread over the banks
-    __shared__ float recs[16 * REC];
+    // The inputs of the workgroup's 16 consecutive knots (and of the knot after them: Q^-1, q and c of knot k+1) are staged in LDS FIELD
+    // by field: each field of 16 (17) consecutive knots is one contiguous, 16-byte aligned run in global memory, copied by the whole
+    // workgroup with 16-byte loads (per knot and lane-group it was ~20 four-byte loads per lane).  A knot's piece of a field starts
+    // at an odd stride (147, 49, 7) or a small even one (14): the 16 groups spread over the banks.
+    __shared__ __attribute__((aligned(16))) float sD[16 * ND];
+    __shared__ __attribute__((aligned(16))) float sQi[17 * NQQ + 3];
+    __shared__ __attribute__((aligned(16))) float sDi[17 * NQ + 1];
+    __shared__ __attribute__((aligned(16))) float sRi[16 * NU];
+    __shared__ __attribute__((aligned(16))) float sQ[17 * NX + 2];
+    __shared__ __attribute__((aligned(16))) float sR[16 * NU];
+    __shared__ __attribute__((aligned(16))) float sC[17 * NX + 2];
     if (bf.ctrl->done) return;
     if constexpr (ROW0) {
         if (blockIdx.y == 1) {  // the Q_0 rows: one lane per trajectory
@@ -1017,23 +1024,26 @@ __global__ __launch_bounds__(256) void schur1_kernel(Buffers bf, int N, int B, f
     const int pidx = g >> 4;
     const int k = pidx % N, b = pidx / N;
     const bool live = b < B && k < N - 1;   // whole groups are in or out; they still reach the barrier
-    const size_t bk = live ? (size_t)b * N + k : 0;
-    float* R = recs + (threadIdx.x >> 4) * REC;
-    if (live) {
-        auto fetch = [&](int off, const float* src, int cnt) {
-            for (int i = l; i < cnt; i += 16) R[off + i] = src[i];
+    {
+        const long total = (long)B * N;
+        const long k0 = (long)blockIdx.x * 16;                       // first knot of the workgroup (flat index b N + k)
+        auto stage = [&](float* dst, const float* field, int per, int knots) {
+            long n = (k0 + knots <= total ? (long)knots : total - k0) * per;   // floats available
+            if (n < 0) n = 0;
+            const float* src = field + k0 * per;                     // k0 is a multiple of 16: 16-byte aligned for every `per`
+            const int n4 = (int)(n / 4);
+            for (int i = threadIdx.x; i < n4; i += blockDim.x) reinterpret_cast<real4*>(dst)[i] = reinterpret_cast<const real4*>(src)[i];
+            for (int i = 4 * n4 + threadIdx.x; i < (int)n; i += blockDim.x) dst[i] = src[i];
         };
-        fetch(0, bf.D + bk * ND, ND);
-        fetch(O_QI, bf.Qqi + bk * NQQ, NQQ);
-        fetch(O_DI, bf.Qdi + bk * NQ, NQ);
-        fetch(O_RI, bf.Rdi + bk * NU, NU);
-        fetch(O_Q, bf.q + bk * NX, NX);
-        fetch(O_R, bf.r + bk * NU, NU);
-        fetch(O_QI1, bf.Qqi + (bk + 1) * NQQ, NQQ);
-        fetch(O_DI1, bf.Qdi + (bk + 1) * NQ, NQ);
-        fetch(O_Q1, bf.q + (bk + 1) * NX, NX);
-        fetch(O_C1, bf.c + (bk + 1) * NX, NX);
+        stage(sD, bf.D, ND, 16);
+        stage(sQi, bf.Qqi, NQQ, 17);
+        stage(sDi, bf.Qdi, NQ, 17);
+        stage(sRi, bf.Rdi, NU, 16);
+        stage(sQ, bf.q, NX, 17);
+        stage(sR, bf.r, NU, 16);
+        stage(sC, bf.c, NX, 17);
     }
+    const int grp = threadIdx.x >> 4;
     __syncthreads();
     if (!live) return;
     const bool act = l < NX;
@@ -1042,7 +1052,7 @@ __global__ __launch_bounds__(256) void schur1_kernel(Buffers bf, int N, int B, f
     const int rm = upper ? y : y - NQ;
     const float h2 = half_dt_sq(dt);
     const float coef = upper ? h2 : dt;
-    const float* Dm = R;
+    const float* Dm = sD + grp * ND;
 
     float Ar[NX], Bri[NU], phi[NX], th[NX], gg;
     {
@@ -1055,16 +1065,16 @@ __global__ __launch_bounds__(256) void schur1_kernel(Buffers bf, int N, int B, f
             Ar[c] = v0 + coef * d;
         }
 #pragma unroll
-        for (int c = 0; c < NU; c++) Bri[c] = (coef * Dm[2 * NQQ + c * NQ + rm]) * R[O_RI + c];
+        for (int c = 0; c < NU; c++) Bri[c] = (coef * Dm[2 * NQQ + c * NQ + rm]) * sRi[grp * NU + c];
     }
     {
 #pragma unroll
         for (int c = 0; c < NQ; c++) {
             float sacc = 0.f;
 #pragma unroll
-            for (int j = 0; j < NQ; j++) sacc += Ar[j] * R[O_QI + c * NQ + j];
+            for (int j = 0; j < NQ; j++) sacc += Ar[j] * sQi[grp * NQQ + c * NQ + j];
             phi[c] = sacc;
-            phi[NQ + c] = Ar[NQ + c] * R[O_DI + c];
+            phi[NQ + c] = Ar[NQ + c] * sDi[grp * NQ + c];
         }
     }
     // own row of Q_{k+1}^-1: tq (q half, zero in qd-half lanes) and the single diagonal entry td (qd half)
@@ -1072,10 +1082,10 @@ __global__ __launch_bounds__(256) void schur1_kernel(Buffers bf, int N, int B, f
     {
 #pragma unroll
         for (int x = 0; x < NQ; x++) {
-            const float v = R[O_QI1 + x * NQ + rm];
+            const float v = sQi[(grp + 1) * NQQ + x * NQ + rm];
             tq[x] = upper ? v : 0.f;
         }
-        const float dv = R[O_DI1 + rm];
+        const float dv = sDi[(grp + 1) * NQ + rm];
         td = upper ? 0.f : dv;
     }
     {
@@ -1099,20 +1109,20 @@ __global__ __launch_bounds__(256) void schur1_kernel(Buffers bf, int N, int B, f
         }
     }
     {
-        const float cy = R[O_C1 + y], qy = R[O_Q1 + y];
+        const float cy = sC[(grp + 1) * NX + y], qy = sQ[(grp + 1) * NX + y];
         float g1 = -1.0f * cy;
         float sq = 0.f;
 #pragma unroll
-        for (int j = 0; j < NQ; j++) sq += tq[j] * R[O_Q1 + j];
+        for (int j = 0; j < NQ; j++) sq += tq[j] * sQ[(grp + 1) * NX + j];
         const float sd = td * qy;
         g1 += upper ? sq : sd;
         float sacc = 0.f;
 #pragma unroll
-        for (int j = 0; j < NX; j++) sacc += phi[j] * R[O_Q + j];
+        for (int j = 0; j < NX; j++) sacc += phi[j] * sQ[grp * NX + j];
         g1 += -sacc;
         sacc = 0.f;
 #pragma unroll
-        for (int j = 0; j < NU; j++) sacc += Bri[j] * R[O_R + j];
+        for (int j = 0; j < NU; j++) sacc += Bri[j] * sR[grp * NU + j];
         g1 += -sacc;
         gg = -1.0f * g1;
     }
