@@ -130,6 +130,7 @@ extern "C" int gato_dims(int plant, int N, int* nq, int* nx, int* nu, int* traj)
 }
 
 static int plan_pcg_dispatch(GatoSolver* s);
+static int sync_last(GatoSolver* s);
 
 static int create_impl(GatoSolver* s, int plant, int N, int B, const GatoParams* params)
 {
@@ -152,6 +153,9 @@ static int create_impl(GatoSolver* s, int plant, int N, int B, const GatoParams*
     s->last_stream = nullptr;
     memset(s->stage_us, 0, sizeof(s->stage_us));
     HIPCHK(hipGetDevice(&s->device));
+    // the stream of the host-buffer entry points: a BLOCKING stream, so the few null-stream operations of the setters / resets (hipMemset,
+    // hipMemcpy) stay ordered with it, while the streams of different handles do not order with each other
+    HIPCHK(hipStreamCreateWithFlags(&s->own_stream, hipStreamDefault));
     const int nq = s->nq, nx = s->nx, nu = s->nu;
     const size_t BN = (size_t)B * N;
     s->max_iters_alloc = params->max_sqp_iters ? params->max_sqp_iters : 1;
@@ -678,21 +682,26 @@ extern "C" int gato_solve(GatoSolver* s, float* xu, float dt, const float* x_s, 
     if (!s || !xu || !x_s || !ref) return fail(GATO_ERR_INVALID, "null argument");
     GUARD(s);
     const size_t nxu = (size_t)s->B * s->traj * sizeof(float);
-    HIPCHK(hipMemcpy(s->d_xu_own, xu, nxu, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(s->d_xs_own, x_s, (size_t)s->B * s->nx * sizeof(float), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(s->d_ref_own, ref, (size_t)s->B * 6 * s->N * sizeof(float), hipMemcpyHostToDevice));
-    HIPCHK(hipDeviceSynchronize());
+    // Everything of this call -- copies in, the launch sequence, copy out -- is ordered on the solver's OWN stream and the host waits on
+    // that stream only: handles that share a device (several MPC solvers, two ranks on one GPU) do not serialise on each other the way a
+    // device-wide synchronisation made them (the reference blocks the whole device: default stream + cudaDeviceSynchronize, bsqp.cuh:184)
+    hipStream_t st = s->own_stream;
+    int rc = sync_last(s);   // a solve enqueued on a caller's stream (gato_solve_device) may still be using the solver's state
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(s->d_xu_own, xu, nxu, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(s->d_xs_own, x_s, (size_t)s->B * s->nx * sizeof(float), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(s->d_ref_own, ref, (size_t)s->B * 6 * s->N * sizeof(float), hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));
     const bool graph = s->graph_mode && !s->profiling;
     if (graph) {
         // (re)capture when something a kernel argument depends on changed; otherwise the instantiated graph is replayed as it is
-        if (!s->own_stream) HIPCHK(hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking));
         const uint32_t iters = s->p.max_sqp_iters <= s->max_iters_alloc ? s->p.max_sqp_iters : s->max_iters_alloc;
         if (!s->graph_exec || s->graph_dt != dt || s->graph_iters != iters || s->graph_adapt != s->adapt_rho || s->graph_lin != s->linear_solver) {
             if (s->graph_exec) { (void)hipGraphExecDestroy(s->graph_exec); s->graph_exec = nullptr; }
             hipGraph_t g = nullptr;
-            HIPCHK(hipStreamBeginCapture(s->own_stream, hipStreamCaptureModeThreadLocal));
-            const int rc_c = solve_dispatch(s, s->d_xu_own, dt, s->d_xs_own, s->d_ref_own, s->own_stream);
-            const hipError_t e_c = hipStreamEndCapture(s->own_stream, &g);
+            HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+            const int rc_c = solve_dispatch(s, s->d_xu_own, dt, s->d_xs_own, s->d_ref_own, st);
+            const hipError_t e_c = hipStreamEndCapture(st, &g);
             if (rc_c != GATO_OK) { if (g) (void)hipGraphDestroy(g); return rc_c; }
             if (e_c != hipSuccess) return fail(GATO_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e_c));
             const hipError_t e_i = hipGraphInstantiate(&s->graph_exec, g, nullptr, nullptr, 0);
@@ -700,22 +709,22 @@ extern "C" int gato_solve(GatoSolver* s, float* xu, float dt, const float* x_s, 
             if (e_i != hipSuccess) { s->graph_exec = nullptr; return fail(GATO_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e_i)); }
             s->graph_dt = dt; s->graph_iters = iters; s->graph_adapt = s->adapt_rho; s->graph_lin = s->linear_solver;
         }
-        s->last_stream = s->own_stream;
+        s->last_stream = st;
         s->last_stream_valid = true;
     }
     auto t0 = std::chrono::high_resolution_clock::now();
     if (graph) {
-        HIPCHK(hipGraphLaunch(s->graph_exec, s->own_stream));
-        HIPCHK(hipStreamSynchronize(s->own_stream));
+        HIPCHK(hipGraphLaunch(s->graph_exec, st));
     } else {
-        int rc = solve_dispatch(s, s->d_xu_own, dt, s->d_xs_own, s->d_ref_own, nullptr);
+        rc = solve_dispatch(s, s->d_xu_own, dt, s->d_xs_own, s->d_ref_own, st);
         if (rc != GATO_OK) return rc;
-        HIPCHK(hipDeviceSynchronize());
     }
+    HIPCHK(hipStreamSynchronize(st));
     auto t1 = std::chrono::high_resolution_clock::now();
     if (sqp_time_us) *sqp_time_us = std::chrono::duration<double, std::micro>(t1 - t0).count();
     collect_profile(s);
-    HIPCHK(hipMemcpy(xu, s->d_xu_own, nxu, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpyAsync(xu, s->d_xu_own, nxu, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
     return GATO_OK;
 }
 
@@ -835,6 +844,7 @@ extern "C" int gato_reset_dual(GatoSolver* s)
     int rc = sync_last(s);
     if (rc) return rc;
     HIPCHK(hipMemset(s->bf.lambda, 0, (size_t)s->B * s->vecp * sizeof(float)));
+    HIPCHK(hipStreamSynchronize(nullptr));   // a device memset is asynchronous to the host: done before a solve on ANY stream can follow
     return GATO_OK;
 }
 extern "C" int gato_reset_rho(GatoSolver* s)

@@ -9,6 +9,8 @@
 #include <type_traits>
 #include <chrono>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -24,6 +26,33 @@
 #endif
 #ifndef KNOT_POINTS
 #define KNOT_POINTS 32
+#endif
+
+// gato/settings.h:7-11: the library-wide real type `T` (namespace sqp, pulled in by `using namespace sqp` like bsqp.cuh:18 does) -- float,
+// or double under the reference's USE_DOUBLES convention, which selects the float64 library here
+#if defined(USE_DOUBLES) && !defined(GATO_DOUBLE)
+#error "USE_DOUBLES needs the float64 ABI: compile with -DGATO_DOUBLE (before gato_abi.h) and link libgato_hip_f64.so"
+#endif
+namespace sqp {
+typedef gato_real T;
+}
+using namespace sqp;
+
+// gato/utils/cuda.cuh:7-19: the example's error check around runtime calls (hip* after the example's cuda* -> hip* renames; the error type
+// is whatever the wrapped call returns, so this header needs no HIP include of its own)
+#ifndef gpuErrchk
+#ifndef NDEBUG
+#define gpuErrchk(ans)                                                                                           \
+    {                                                                                                            \
+        const auto gato_err_ = (ans);                                                                            \
+        if (static_cast<int>(gato_err_) != 0) {                                                                  \
+            std::fprintf(stderr, "GPUassert: error %d %s %d\n", static_cast<int>(gato_err_), __FILE__, __LINE__); \
+            std::exit(static_cast<int>(gato_err_));                                                              \
+        }                                                                                                        \
+    }
+#else
+#define gpuErrchk(ans) ans
+#endif
 #endif
 
 template<typename T, uint32_t BatchSize>

@@ -67,3 +67,28 @@ def test_cpp_example_equals_python_path(tmp_path, f64):
     np.testing.assert_array_equal(merit_c, rp["final_merit"])
     np.testing.assert_array_equal(next_c, s.sim_forward(x0, np.array([1.0, -2.0, 0.5, 0.1, -0.1, 0.05], np.float32), c(0.01)))
     assert meta[0] > 0 and int(meta[1]) == 4 and int(meta[2]) == rp["ls_num_iters"] and T(meta[3]) == rp["ls_step_size"][-1][0]
+
+
+REF_EXAMPLE = "/root/reference/examples/bsqp.cu"
+
+
+@pytest.mark.skipif(not os.path.exists(REF_EXAMPLE), reason="the reference tree is only present in the build container")
+@pytest.mark.parametrize("f64", [False, True])
+def test_the_reference_example_itself_compiles_after_renames(tmp_path, f64):
+    """SURVEY 8(b)4 literally: the reference's examples/bsqp.cu, read at test time (never committed), with ONLY its cuda* -> hip* renames and
+    its three gato includes pointed at include/bsqp.hpp, compiles and links against this library -- `T` (settings.h:7-11), `gpuErrchk`
+    (utils/cuda.cuh:7-19), the 15-scalar constructor, ProblemInputs / SQPStats and the device-pointer solve are all the header's."""
+    import re
+    src = open(REF_EXAMPLE).read()
+    src = re.sub(r'#include "bsqp/bsqp\.cuh"', '#include <hip/hip_runtime.h>\n#include "bsqp.hpp"', src)
+    src = re.sub(r'#include "(types|utils/cuda)\.cuh"\n', "", src)
+    src = re.sub(r"\bcuda([A-Z])", r"hip\1", src)
+    assert "cuda" not in src and ".cuh" not in src
+    cpp = tmp_path / "reference_example.cpp"
+    cpp.write_text(src)
+    exe = str(tmp_path / "reference_example")
+    flags = ["-DUSE_DOUBLES", "-DGATO_DOUBLE"] if f64 else []
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-std=c++17", "-O1", "--offload-arch=gfx950", "-DPLANT_INDY7", "-DKNOT_POINTS=16", "-Wno-unused-result",
+                           "-I", os.path.join(ROOT, "include"), str(cpp), "-o", exe, "-L" + LIBDIR, "-lgato_hip_f64" if f64 else "-lgato_hip",
+                           "-Wl,-rpath," + LIBDIR] + flags)
+    assert os.path.exists(exe)

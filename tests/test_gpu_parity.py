@@ -384,14 +384,23 @@ def test_solver_state_semantics():
 
 
 def test_early_exit_on_device():
+    """the two trivial regimes of the exit rule, HIP and oracle side by side (the non-trivial ones -- a strict subset converged, exits in
+    later iterations, 0 < solve_ratio < 1 -- are tests/test_convergence_gpu.py)"""
     nat, orc, pr = make("indy7", 8, 2, 0.0, max_sqp_iters=3, solve_ratio=0.0)
     rg = nat.solve(pr["xu"], DT, pr["x_s"], pr["ref"])
-    assert rg["iters_done"] == 1 and rg["ls_num_iters"] == 0 and np.all(rg["sqp_iters"] == 1)
+    ro = orc.solve(pr["xu"], DT, pr["x_s"], pr["ref"])
+    assert rg["iters_done"] == 1 == ro["iters_done"] and rg["ls_num_iters"] == 0 == ro["ls_num_iters"] and np.all(rg["sqp_iters"] == 1)
+    np.testing.assert_array_equal(rg["sqp_iters"], ro["sqp_iters"])
+    np.testing.assert_array_equal(rg["kkt_converged"], ro["kkt_converged"])
     np.testing.assert_array_equal(rg["XU"], pr["xu"])
-    assert rg["pcg_iters"].shape[0] == 0 and rg["pcg_iters_all"].shape == (1, 2)
+    np.testing.assert_array_equal(ro["XU"], pr["xu"])
+    assert rg["pcg_iters"].shape[0] == 0 and rg["pcg_iters_all"].shape == (1, 2) == ro["pcg_iters_all"].shape
+    assert np.abs(rg["pcg_iters_all"].astype(int) - ro["pcg_iters_all"]).max() <= 1
     nat2, orc2, pr2 = make("indy7", 8, 2, 0.0, max_sqp_iters=3, pcg_tol=1e6)
     r2 = nat2.solve(pr2["xu"], DT, pr2["x_s"], pr2["ref"])
-    assert np.all(r2["pcg_iters"] == 1) and r2["iters_done"] == 3
+    o2 = orc2.solve(pr2["xu"], DT, pr2["x_s"], pr2["ref"])
+    assert np.all(r2["pcg_iters"] == 1) and r2["iters_done"] == 3 == o2["iters_done"] and np.array_equal(r2["pcg_iters"], o2["pcg_iters"])
+    np.testing.assert_array_equal(r2["kkt_converged"], o2["kkt_converged"])
 
 
 @pytest.mark.parametrize("plant,N,B", [("indy7", 32, 700), ("iiwa14", 64, 300), ("indy7", 16, 40)])

@@ -167,3 +167,39 @@ def test_per_trajectory_cost_weights_equal_one_solver_per_tuple():
         s = OracleSolver("indy7", N, 1, dt=dt, **pi)
         ri = s.solve(pr["xu"][i:i + 1], dt, pr["x_s"][i:i + 1], pr["ref"][i:i + 1])
         np.testing.assert_array_equal(ri["XU"][0], r1["XU"][i])
+
+
+@pytest.mark.parametrize("plant,N", [("iiwa14", 8), ("indy7", 32), ("iiwa14", 16)])
+def test_mixed_batch_convergence_and_solve_ratio(plant, N):
+    """bsqp.cuh:142-167 / pcg.cuh:29-32 where they act (tests/mixed_batch.py): a strict subset converged at entry (E, U rows), rows that converge
+    later (P), rows that never do (F); solve_ratio values that exit in the first, in a later and in no iteration.  The same cases run on the
+    device against this oracle in tests/test_convergence_gpu.py."""
+    from mixed_batch import check_record_semantics, mixed_problem
+    from oracle import oracle as O
+    pr = mixed_problem(plant, N, ee=lambda p, q: O.ee(p, q)[0])
+    kinds = pr["kinds"]
+    B, iters = len(kinds), 6
+    out = {}
+    for ratio in (0.3, 0.5, 1.0):
+        for f64 in (False, True):
+            p = dict(DEFAULT_SOLVER_PARAMS, max_sqp_iters=iters, solve_ratio=ratio, pcg_tol=1e-8, max_pcg_iters=1000)
+            s = OracleSolver(plant, N, B, dt=0.01, f64=f64, **p)
+            s.set_f_ext_batch(pr["f_ext"]); s.set_cost_weights_batch(pr["w"])
+            r = out[ratio, f64] = s.solve(pr["xu"], 0.01, pr["x_s"], pr["ref"])
+            check_record_semantics(r, B, ratio, iters)
+            np.testing.assert_array_equal(r["pcg_iters_all"][0] == 0, np.array([k in "EU" for k in kinds]))
+        a, b = out[ratio, False], out[ratio, True]     # fp32 and float64 agree on every counter and flag
+        assert a["iters_done"] == b["iters_done"] and a["ls_num_iters"] == b["ls_num_iters"]
+        np.testing.assert_array_equal(a["kkt_converged"], b["kkt_converged"])
+        np.testing.assert_array_equal(a["pcg_iters_all"] == 0, b["pcg_iters_all"] == 0)
+    r = out[0.3, False]
+    assert r["iters_done"] == 1 and r["ls_num_iters"] == 0 and r["pcg_iters"].shape[0] == 0     # one PCG record more than line searches, truncated
+    np.testing.assert_array_equal(r["XU"], pr["xu"])
+    r = out[0.5, False]
+    assert 2 <= r["iters_done"] < iters and r["ls_num_iters"] == r["iters_done"] - 1               # exit in a later iteration
+    r = out[1.0, False]
+    u = np.array([k == "U" for k in kinds])
+    assert r["iters_done"] == iters and 0 < r["kkt_converged"].sum() < B
+    assert np.all(r["ls_step_size"][0][u] == 1.0) and np.all(np.abs(r["XU"][u] - pr["xu"][u]).max(axis=1) > 0.1)   # converged at entry and still moved
+    e = np.array([k == "E" for k in kinds])
+    assert np.abs(r["XU"][e] - pr["xu"][e]).max() < 1e-5
