@@ -20,6 +20,7 @@ SYMBOLS = [
     "gato_last_error", "gato_version", "gato_reset_async", "gato_copy_final_merit_device", "gato_set_cost_weights_batch",
     "gato_synchronize", "gato_sim_forward_device", "gato_select_best", "gato_select_best_device",
     "gato_plant_rk4", "gato_fk_placements", "gato_set_linear_solver", "gato_set_graph_mode",
+    "gato_mpc_begin", "gato_mpc_step", "gato_mpc_get_best",
 ]
 
 
@@ -28,6 +29,14 @@ def _params_struct(ft, name):
         ("dt", ft), ("max_sqp_iters", C.c_uint32), ("kkt_tol", ft), ("max_pcg_iters", C.c_uint32), ("pcg_tol", ft), ("solve_ratio", ft),
         ("mu", ft), ("q_cost", ft), ("qd_cost", ft), ("u_cost", ft), ("N_cost", ft), ("q_lim_cost", ft), ("vel_lim_cost", ft),
         ("ctrl_lim_cost", ft), ("rho", ft)]})
+
+
+def _mpc_struct(ft, name):
+    """GatoMpcStep of include/gato_abi.h"""
+    return type(name, (C.Structure,), {"_fields_": [
+        ("phases", C.c_int32), ("plant_steps", C.c_int32), ("sim_dt", ft), ("steps_per_knot", C.c_double), ("plant_wrench", ft * 6),
+        ("ref_window", C.POINTER(ft)), ("hyp_world", C.POINTER(ft)), ("select", C.c_int32), ("select_dt", ft), ("x", ft * 16), ("ee", ft * 3),
+        ("best", C.c_int32), ("solve_us", C.c_double), ("errors", C.POINTER(ft))]})
 
 
 GatoParams = _params_struct(C.c_float, "GatoParams")
@@ -68,7 +77,11 @@ def load(f64=False):
     ft = C.c_double if f64 else C.c_float
     PT = GatoParamsF64 if f64 else GatoParams
     L._ft, L._np, L._PT = ft, (np.float64 if f64 else np.float32), PT
+    L._MPC = _mpc_struct(ft, "GatoMpcStepF64" if f64 else "GatoMpcStep")
     fp, ip, vp = C.POINTER(ft), C.POINTER(C.c_int32), C.c_void_p
+    L.gato_mpc_begin.argtypes = [vp, fp]
+    L.gato_mpc_step.argtypes = [vp, C.POINTER(L._MPC)]
+    L.gato_mpc_get_best.argtypes = [vp, fp]
     L.gato_default_params.argtypes = [C.POINTER(PT)]
     L.gato_default_params.restype = None
     L.gato_dims.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
@@ -299,6 +312,35 @@ class NativeSolver:
         u = self._f(u_seq).reshape(-1, self.nu)
         self._chk(self.L.gato_plant_rk4(self.h, self._p(x), self._p(u), int(u.shape[0]), self._p(self._f(f_ext6, (6,))), float(sim_dt)))
         return x
+
+    # ---- MPC session (gato_mpc_*): one call per MPC step, the loop's state stays on the device ----
+    def mpc_begin(self, x0):
+        self._chk(self.L.gato_mpc_begin(self.h, self._p(self._f(x0, (self.nx,)))))
+
+    def mpc_step(self, advance=True, plan=True, plant_steps=0, sim_dt=0.001, steps_per_knot=1.0, plant_wrench=None, ref_window=None, hyp_world=None,
+                 select=False, select_dt=0.0):
+        io = self.L._MPC()
+        io.phases = (1 if advance else 0) | (2 if plan else 0)
+        io.plant_steps, io.sim_dt, io.steps_per_knot = int(plant_steps), float(sim_dt), float(steps_per_knot)
+        fw = self._f(np.zeros(6) if plant_wrench is None else plant_wrench, (6,))
+        for i in range(6):
+            io.plant_wrench[i] = float(fw[i])
+        keep = []
+        if ref_window is not None:
+            rw = self._f(ref_window, (6 * self.N,)); keep.append(rw); io.ref_window = self._p(rw)
+        if hyp_world is not None:
+            hw = self._f(hyp_world, (6 * self.B,)); keep.append(hw); io.hyp_world = self._p(hw)
+        io.select, io.select_dt = int(bool(select)), float(select_dt)
+        err = np.zeros(self.B, self.dtype)
+        io.errors = self._p(err)
+        self._chk(self.L.gato_mpc_step(self.h, C.byref(io)))
+        return {"x": np.array(io.x[: self.nx], self.dtype), "ee": np.array(io.ee[:3], self.dtype), "best": int(io.best), "solve_us": float(io.solve_us),
+                "errors": err}
+
+    def mpc_best(self):
+        out = np.zeros(self.traj, self.dtype)
+        self._chk(self.L.gato_mpc_get_best(self.h, self._p(out)))
+        return out
 
     def synchronize(self):
         self._chk(self.L.gato_synchronize(self.h))

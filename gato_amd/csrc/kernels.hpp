@@ -2854,6 +2854,47 @@ __global__ __launch_bounds__(256) void select_best_kernel(float* __restrict__ xk
     }
 }
 
+// one RK4 step of size h of the arm's forward dynamics under the control u and the wrench fe (common.py:49-91 `rk4`)
+template<class M> GATO_DEV void plant_rk4_step(float* q, float* v, const float* u, const float* fe, float h)
+{
+    constexpr int NQ = M::NQ;
+    const float hh = 0.5f * h;
+    float k1v[NQ], k2v[NQ], k3v[NQ], k4v[NQ], k2q[NQ], k3q[NQ], k4q[NQ], qs[NQ];
+    {
+        RBD<M> d;
+        d.set_q(q);
+        d.forward_dynamics(v, u, fe, k1v);
+    }
+#pragma unroll
+    for (int i = 0; i < NQ; i++) { qs[i] = q[i] + v[i] * hh; k2q[i] = v[i] + k1v[i] * hh; }
+    {
+        RBD<M> d;
+        d.set_q(qs);
+        d.forward_dynamics(k2q, u, fe, k2v);
+    }
+#pragma unroll
+    for (int i = 0; i < NQ; i++) { qs[i] = q[i] + k2q[i] * hh; k3q[i] = v[i] + k2v[i] * hh; }
+    {
+        RBD<M> d;
+        d.set_q(qs);
+        d.forward_dynamics(k3q, u, fe, k3v);
+    }
+#pragma unroll
+    for (int i = 0; i < NQ; i++) { qs[i] = q[i] + k3q[i] * h; k4q[i] = v[i] + k3v[i] * h; }
+    {
+        RBD<M> d;
+        d.set_q(qs);
+        d.forward_dynamics(k4q, u, fe, k4v);
+    }
+#pragma unroll
+    for (int i = 0; i < NQ; i++) {
+        const float avg = (v[i] + 2.f * k2q[i] + 2.f * k3q[i] + k4q[i]) / 6.f;
+        const float vn = v[i] + (h / 6.f) * (k1v[i] + 2.f * k2v[i] + 2.f * k3v[i] + k4v[i]);
+        q[i] = q[i] + avg * h;
+        v[i] = vn;
+    }
+}
+
 // The plant of the closed MPC loop: `nsteps` RK4 steps of the arm's forward dynamics under a constant wrench on the last link, one
 // control vector per step -- what python/bsqp/common.py:49-91 (`rk4`: k1..k4 from the articulated-body forward dynamics, revolute
 // joints so pin.integrate is q + v h) does with pinocchio between two solves of MPC_GATO.run_mpc_fig8 (mpc_controller.py:199-218).
@@ -2870,45 +2911,11 @@ __global__ __launch_bounds__(64) void plant_rk4_kernel(float* __restrict__ x_io,
     for (int i = 0; i < NQ; i++) { q[i] = x_io[(size_t)p * NX + i]; v[i] = x_io[(size_t)p * NX + NQ + i]; }
 #pragma unroll
     for (int i = 0; i < 6; i++) fe[i] = f_ext[6 * p + i];
-    const float hh = 0.5f * h;
     for (int s = 0; s < nsteps; s++) {
         float u[NQ];
 #pragma unroll
         for (int i = 0; i < NQ; i++) u[i] = u_seq[((size_t)p * nsteps + s) * NQ + i];
-        float k1v[NQ], k2v[NQ], k3v[NQ], k4v[NQ], k2q[NQ], k3q[NQ], k4q[NQ], qs[NQ];
-        {
-            RBD<M> d;
-            d.set_q(q);
-            d.forward_dynamics(v, u, fe, k1v);
-        }
-#pragma unroll
-        for (int i = 0; i < NQ; i++) { qs[i] = q[i] + v[i] * hh; k2q[i] = v[i] + k1v[i] * hh; }
-        {
-            RBD<M> d;
-            d.set_q(qs);
-            d.forward_dynamics(k2q, u, fe, k2v);
-        }
-#pragma unroll
-        for (int i = 0; i < NQ; i++) { qs[i] = q[i] + k2q[i] * hh; k3q[i] = v[i] + k2v[i] * hh; }
-        {
-            RBD<M> d;
-            d.set_q(qs);
-            d.forward_dynamics(k3q, u, fe, k3v);
-        }
-#pragma unroll
-        for (int i = 0; i < NQ; i++) { qs[i] = q[i] + k3q[i] * h; k4q[i] = v[i] + k3v[i] * h; }
-        {
-            RBD<M> d;
-            d.set_q(qs);
-            d.forward_dynamics(k4q, u, fe, k4v);
-        }
-#pragma unroll
-        for (int i = 0; i < NQ; i++) {
-            const float avg = (v[i] + 2.f * k2q[i] + 2.f * k3q[i] + k4q[i]) / 6.f;
-            const float vn = v[i] + (h / 6.f) * (k1v[i] + 2.f * k2v[i] + 2.f * k3v[i] + k4v[i]);
-            q[i] = q[i] + avg * h;
-            v[i] = vn;
-        }
+        plant_rk4_step<M>(q, v, u, fe, h);
     }
 #pragma unroll
     for (int i = 0; i < NQ; i++) { x_io[(size_t)p * NX + i] = q[i]; x_io[(size_t)p * NX + NQ + i] = v[i]; }
@@ -2928,6 +2935,138 @@ __global__ __launch_bounds__(256) void ee_pos_kernel(float* __restrict__ out, co
     d.set_q(qq);
     d.ee_pos(e);
     out[3 * g] = e[0]; out[3 * g + 1] = e[1]; out[3 * g + 2] = e[2];
+}
+
+// =========================================================================================================================
+// MPC session (gato_mpc_begin / gato_mpc_step): the closed loop of python/bsqp/mpc_controller.py:196-242 with the measured state, the
+// best trajectory and the batch iterates RESIDENT on the device -- one host call per MPC step enqueues, on one stream:
+//   mpc_plant_kernel     the plant over the measured interval (RK4, the controls read from the best trajectory by knot index)
+//   mpc_prepare_kernel   every row := best trajectory with its first state := the measured one; x_s, the reference window and the
+//                        wrench hypotheses (world frame -> last joint frame, mpc_controller.py:311-338) broadcast / transformed per row
+//   the SQP solve        (solver.hip:solve_impl, unchanged)
+//   select_best_kernel   hypothesis selection (mpc_controller.py:294-309), then mpc_take_best_kernel copies the winner
+// =========================================================================================================================
+// rows := warm start (x0 repeated over the knots, zero controls: common.py:93-99), best := the same, state := x0
+template<class M>
+__global__ __launch_bounds__(256) void mpc_warm_kernel(float* __restrict__ xu, float* __restrict__ xu_best, float* __restrict__ x, const float* __restrict__ x0,
+                                                       int traj, int B)
+{
+    constexpr int NX = 2 * M::NQ, KS = 3 * M::NQ;
+    const int b = blockIdx.x;   // b == B: the best-trajectory buffer and the state
+    float* dst = b < B ? xu + (size_t)b * traj : xu_best;
+    for (int i = threadIdx.x; i < traj; i += blockDim.x) {
+        const int o = i % KS;
+        dst[i] = o < NX ? x0[o] : 0.f;
+    }
+    if (b == B && threadIdx.x < NX) x[threadIdx.x] = x0[threadIdx.x];
+}
+
+// x_last := x; x := the plant after nsteps RK4 steps of size h under the wrench fe6, step i driven by the control of knot
+// min(int(i / steps_per_knot), N - 1) of the best trajectory (mpc_controller.py:199-218; the quotient in double like the Python it mirrors)
+template<class M>
+__global__ __launch_bounds__(64) void mpc_plant_kernel(float* __restrict__ x, float* __restrict__ x_last, const float* __restrict__ xu_best,
+                                                       const float* __restrict__ fe6, int nsteps, float h, double steps_per_knot, int N)
+{
+    constexpr int NQ = M::NQ, NX = 2 * NQ, KS = 3 * NQ;
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    float q[NQ], v[NQ], fe[6];
+#pragma unroll
+    for (int i = 0; i < NQ; i++) { q[i] = x[i]; v[i] = x[NQ + i]; x_last[i] = q[i]; x_last[NQ + i] = v[i]; }
+#pragma unroll
+    for (int i = 0; i < 6; i++) fe[i] = fe6[i];
+    for (int s = 0; s < nsteps; s++) {
+        int k = (int)((double)s / steps_per_knot);
+        k = k < N - 1 ? k : N - 1;
+        float u[NQ];
+#pragma unroll
+        for (int i = 0; i < NQ; i++) u[i] = xu_best[(size_t)k * KS + NX + i];
+        plant_rk4_step<M>(q, v, u, fe, h);
+    }
+#pragma unroll
+    for (int i = 0; i < NQ; i++) { x[i] = q[i]; x[NQ + i] = v[i]; }
+}
+
+// MPC_GATO.transform_force_to_gato_frame (mpc_controller.py:311-338) on the library's own kinematics: the world-frame wrench
+// (linear fw[0:3], angular fw[3:6]) expressed in the last joint's frame -- SE3.actInv with that joint's world placement -- and then
+// actInv of the joint's placement in its parent.  R_ee^T w = E_{n-1} ... E_0 w with E_k = Ez(q_k) E0_k (rbd.hpp), p_ee = the end effector,
+// the local placement is (E_{n-1}^T, r_{n-1}).  Returned as [linear, angular], the order the reference hands to set_f_ext_batch.
+template<class M, int K = 0> GATO_DEV void world_to_last_frame(const RBD<M>& d, float* w)
+{
+    if constexpr (K < M::NQ) {
+        float t[3];
+        d.template Emul<K>(w, t);
+        w[0] = t[0]; w[1] = t[1]; w[2] = t[2];
+        world_to_last_frame<M, K + 1>(d, w);
+    }
+}
+template<class M> GATO_DEV void force_to_gato_frame(const float* q, const float* fw, float* out)
+{
+    constexpr int L = M::NQ - 1;
+    RBD<M> d;
+    d.set_q(q);
+    float pe[3];
+    d.ee_pos(pe);
+    float lin[3] = {fw[0], fw[1], fw[2]};
+    float ang[3] = {fw[3] - (pe[1] * fw[2] - pe[2] * fw[1]), fw[4] - (pe[2] * fw[0] - pe[0] * fw[2]), fw[5] - (pe[0] * fw[1] - pe[1] * fw[0])};
+    world_to_last_frame<M>(d, lin);
+    world_to_last_frame<M>(d, ang);
+    float rl[3], t[3], lin2[3], ang2[3];
+    d.template rcross<L>(lin, rl);                       // r_L x lin
+    t[0] = ang[0] - rl[0]; t[1] = ang[1] - rl[1]; t[2] = ang[2] - rl[2];
+    d.template Emul<L>(lin, lin2);
+    d.template Emul<L>(t, ang2);
+    out[0] = lin2[0]; out[1] = lin2[1]; out[2] = lin2[2];
+    out[3] = ang2[0]; out[4] = ang2[1]; out[5] = ang2[2];
+}
+
+// one workgroup per row b: xu_b := best trajectory, its first state := x; x_s_b := x; ref_b := the window; f_ext_b := hypothesis b in the
+// last joint's frame (hyp_world == nullptr: the stored wrenches stay)
+template<class M>
+__global__ __launch_bounds__(256) void mpc_prepare_kernel(float* __restrict__ xu, float* __restrict__ x_s, float* __restrict__ ref, float* __restrict__ f_ext,
+                                                          const float* __restrict__ xu_best, const float* __restrict__ x, const float* __restrict__ refw,
+                                                          const float* __restrict__ hyp_world, int N, int traj)
+{
+    constexpr int NQ = M::NQ, NX = 2 * NQ;
+    const int b = blockIdx.x;
+    for (int i = threadIdx.x; i < traj; i += blockDim.x) xu[(size_t)b * traj + i] = i < NX ? x[i] : xu_best[i];
+    for (int i = threadIdx.x; i < 6 * N; i += blockDim.x) ref[(size_t)b * 6 * N + i] = refw[i];
+    if (threadIdx.x < NX) x_s[(size_t)b * NX + threadIdx.x] = x[threadIdx.x];
+    if (hyp_world != nullptr && threadIdx.x == 64) {   // a lane of the second wavefront: beside the copies, not behind them
+        float q[NQ], fw[6], o[6];
+#pragma unroll
+        for (int i = 0; i < NQ; i++) q[i] = x[i];
+#pragma unroll
+        for (int i = 0; i < 6; i++) fw[i] = hyp_world[6 * b + i];
+        force_to_gato_frame<M>(q, fw, o);
+#pragma unroll
+        for (int i = 0; i < 6; i++) f_ext[6 * b + i] = o[i];
+    }
+}
+
+// best trajectory := row *best of the batch (the winner of select_best_kernel; row 0 without a selection)
+__global__ __launch_bounds__(256) void mpc_take_best_kernel(float* __restrict__ xu_best, const float* __restrict__ xu, const int32_t* __restrict__ best, int traj, int B)
+{
+    int w = best ? *best : 0;
+    w = (w < 0 || w >= B) ? 0 : w;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < traj; i += gridDim.x * blockDim.x) xu_best[i] = xu[(size_t)w * traj + i];
+}
+
+// end effector of the session's state + the packed record the host reads back: [x (nx) | ee (3) | best (int bits)]
+template<class M>
+__global__ __launch_bounds__(64) void mpc_report_kernel(float* __restrict__ rec, const float* __restrict__ x, const int32_t* __restrict__ best)
+{
+    constexpr int NQ = M::NQ, NX = 2 * NQ;
+    if (threadIdx.x != 0) return;
+    float q[NQ], e[3];
+#pragma unroll
+    for (int i = 0; i < NQ; i++) q[i] = x[i];
+    RBD<M> d;
+    d.set_q(q);
+    d.ee_pos(e);
+#pragma unroll
+    for (int i = 0; i < NX; i++) rec[i] = x[i];
+    rec[NX] = e[0]; rec[NX + 1] = e[1]; rec[NX + 2] = e[2];
+    rec[NX + 3] = (float)(best ? *best : 0);
 }
 
 }  // namespace gato

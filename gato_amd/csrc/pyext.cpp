@@ -188,6 +188,74 @@ class PyBSQP {
         return out;
     }
 
+    // ---- MPC session (gato_mpc_*, include/gato_abi.h): one call per MPC step, the loop's state stays on the device
+    void mpc_begin(farray x0) { chk(gato_mpc_begin(s_, need(x0, nx_, "x0"))); }
+    py::dict mpc_step(bool advance, bool plan, int plant_steps, float sim_dt, double steps_per_knot, py::object plant_wrench, py::object ref_window,
+                      py::object hyp_world, bool select, float select_dt)
+    {
+        GatoMpcStep io;
+        std::memset(&io, 0, sizeof(io));
+        io.phases = (advance ? GATO_MPC_ADVANCE : 0) | (plan ? GATO_MPC_PLAN : 0);
+        io.plant_steps = plant_steps;
+        io.sim_dt = sim_dt;
+        io.steps_per_knot = steps_per_knot;
+        farray fw, rw, hw;   // keep the converted arrays alive for the call
+        if (!plant_wrench.is_none()) {
+            fw = plant_wrench.cast<farray>();
+            std::memcpy(io.plant_wrench, need(fw, 6, "plant_wrench"), 6 * sizeof(float));
+        }
+        if (!ref_window.is_none()) {
+            rw = ref_window.cast<farray>();
+            io.ref_window = need(rw, (size_t)6 * N_, "ref_window");
+        }
+        if (!hyp_world.is_none()) {
+            hw = hyp_world.cast<farray>();
+            io.hyp_world = need(hw, (size_t)6 * B_, "hyp_world");
+        }
+        io.select = select ? 1 : 0;
+        io.select_dt = select_dt;
+        py::array_t<float> err((py::ssize_t)B_);
+        io.errors = err.mutable_data();
+        {
+            py::gil_scoped_release nogil;
+            chk(gato_mpc_step(s_, &io));
+        }
+        py::array_t<float> x((py::ssize_t)nx_), ee((py::ssize_t)3);
+        std::memcpy(x.mutable_data(), io.x, nx_ * sizeof(float));
+        std::memcpy(ee.mutable_data(), io.ee, 3 * sizeof(float));
+        py::dict r;
+        r["x"] = x;
+        r["ee"] = ee;
+        r["best"] = (int)io.best;
+        r["solve_us"] = io.solve_us;
+        r["errors"] = err;
+        return r;
+    }
+    py::array_t<float> mpc_best()
+    {
+        py::array_t<float> out((py::ssize_t)traj_);
+        chk(gato_mpc_get_best(s_, out.mutable_data()));
+        return out;
+    }
+    // the statistics of the last solve without another solve (the MPC session solves inside gato_mpc_step)
+    py::dict last_stats()
+    {
+        uint32_t iters = 0, ls = 0;
+        chk(gato_get_counts(s_, &iters, &ls));
+        py::array_t<int32_t> sqp_iters((py::ssize_t)B_);
+        chk(gato_get_sqp_iters(s_, sqp_iters.mutable_data()));
+        std::vector<int32_t> pcg((size_t)(iters ? iters : 1) * B_);
+        chk(gato_get_pcg_iters(s_, pcg.data()));
+        py::array_t<int32_t> pa({(py::ssize_t)iters, (py::ssize_t)B_});
+        if (iters) std::memcpy(pa.mutable_data(), pcg.data(), (size_t)iters * B_ * sizeof(int32_t));
+        py::dict r;
+        r["sqp_iters"] = sqp_iters;
+        r["pcg_iters_all"] = pa;
+        r["iters_done"] = (int)iters;
+        r["ls_num_iters"] = (int)ls;
+        return r;
+    }
+
     int knot_points() const { return N_; }
     int batch_size() const { return B_; }
     std::string plant() const { return plant_; }
@@ -252,6 +320,11 @@ PYBIND11_MODULE(GATO_EXT_NAME, m)
         .def("ee_pos", &PyBSQP::ee_pos)
         .def("select_best", &PyBSQP::select_best)
         .def("plant_rk4", &PyBSQP::plant_rk4)
+        .def("mpc_begin", &PyBSQP::mpc_begin)
+        .def("mpc_step", &PyBSQP::mpc_step, py::arg("advance"), py::arg("plan"), py::arg("plant_steps"), py::arg("sim_dt"), py::arg("steps_per_knot"),
+             py::arg("plant_wrench"), py::arg("ref_window"), py::arg("hyp_world"), py::arg("select"), py::arg("select_dt"))
+        .def("mpc_best", &PyBSQP::mpc_best)
+        .def("last_stats", &PyBSQP::last_stats)
         .def_property_readonly("knot_points", &PyBSQP::knot_points)
         .def_property_readonly("batch_size", &PyBSQP::batch_size)
         .def_property_readonly("plant", &PyBSQP::plant)

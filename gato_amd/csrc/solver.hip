@@ -84,6 +84,10 @@ struct GatoSolver {
     float *d_ee_q, *d_ee_out;              // staging of ee_pos, grown on demand
     size_t ee_cap;
     float* d_plant;                        // staging of gato_plant_rk4 (x | wrench | control sequence), grown on demand
+    // MPC session (gato_mpc_*): state, previous state, best trajectory, reference window, world-frame hypotheses, plant wrench, record
+    float *d_mpc_x, *d_mpc_xlast, *d_mpc_best, *d_mpc_refw, *d_mpc_hyp, *d_mpc_fw, *d_mpc_rec;
+    hipEvent_t mpc_ev0, mpc_ev1;
+    bool mpc_begun = false;
     size_t plant_cap;
     uint32_t max_iters_alloc;
     Buffers bf;
@@ -191,11 +195,14 @@ static int create_impl(GatoSolver* s, int plant, int N, int B, const GatoParams*
     DA(s->d_merit_init0, B); DA(s->d_drho_init, B); DA(s->d_rho_init, B);
     DA(s->d_sim_x, nx); DA(s->d_sim_u, nu); DA(s->d_sim_out, (size_t)B * nx);
     DA(s->d_sel_xm, nx); DA(s->d_sel_err, B); DA(s->d_sel_best, 2);
+    DA(s->d_mpc_x, nx); DA(s->d_mpc_xlast, nx); DA(s->d_mpc_best, s->traj); DA(s->d_mpc_refw, 6 * (size_t)N); DA(s->d_mpc_hyp, 6 * (size_t)B);
+    DA(s->d_mpc_fw, 6); DA(s->d_mpc_rec, nx + 4);
 #undef DA
     s->d_ee_q = s->d_ee_out = nullptr;
     s->ee_cap = 0;
     s->d_plant = nullptr;
     s->plant_cap = 0;
+    s->mpc_ev0 = s->mpc_ev1 = nullptr;
     // per-trajectory defaults (bsqp.cuh:48-58)
     s->h_rho_init.assign(B, params->rho);
     s->h_drho_init.assign(B, 1.0f);
@@ -254,6 +261,8 @@ extern "C" int gato_destroy(GatoSolver* s)
     if (s->d_ee_out) (void)hipFree(s->d_ee_out);
     if (s->d_plant) (void)hipFree(s->d_plant);
     if (s->graph_exec) (void)hipGraphExecDestroy(s->graph_exec);
+    if (s->mpc_ev0) (void)hipEventDestroy(s->mpc_ev0);
+    if (s->mpc_ev1) (void)hipEventDestroy(s->mpc_ev1);
     if (s->own_stream) (void)hipStreamDestroy(s->own_stream);
     for (void* p : s->allocs) (void)hipFree(p);
     for (hipEvent_t e : s->events) (void)hipEventDestroy(e);
@@ -1044,6 +1053,107 @@ extern "C" int gato_ee_pos(GatoSolver* s, const float* q, int n, float* out)
     else hipLaunchKernelGGL((ee_pos_kernel<Iiwa14>), dim3(cdiv(n, 256)), dim3(256), 0, nullptr, s->d_ee_out, s->d_ee_q, n);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpy(out, s->d_ee_out, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    return GATO_OK;
+}
+
+// ---- MPC session (include/gato_abi.h) -------------------------------------------------------------------------------------------------
+template<class M> static int mpc_begin_impl(GatoSolver* s, const float* x0)
+{
+    hipStream_t st = s->own_stream;
+    HIPCHK(hipMemcpyAsync(s->d_sel_xm, x0, s->nx * sizeof(float), hipMemcpyHostToDevice, st));   // staging for x0
+    hipLaunchKernelGGL((mpc_warm_kernel<M>), dim3(s->B + 1), dim3(256), 0, st, s->d_xu_own, s->d_mpc_best, s->d_mpc_x, (const float*)s->d_sel_xm, s->traj, s->B);
+    HIPCHK(hipMemsetAsync(s->bf.lambda, 0, (size_t)s->B * s->vecp * sizeof(float), st));         // reset_dual (mpc_controller.py:172)
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));
+    return GATO_OK;
+}
+extern "C" int gato_mpc_begin(GatoSolver* s, const float* x0)
+{
+    if (!s || !x0) return fail(GATO_ERR_INVALID, "null argument");
+    GUARD(s);
+    int rc = sync_last(s);
+    if (rc) return rc;
+    if (!s->mpc_ev0) { HIPCHK(hipEventCreate(&s->mpc_ev0)); HIPCHK(hipEventCreate(&s->mpc_ev1)); }
+    rc = s->plant == GATO_PLANT_INDY7 ? mpc_begin_impl<Indy7>(s, x0) : mpc_begin_impl<Iiwa14>(s, x0);
+    if (rc == GATO_OK) s->mpc_begun = true;
+    return rc;
+}
+template<class M> static int mpc_step_impl(GatoSolver* s, GatoMpcStep* io)
+{
+    hipStream_t st = s->own_stream;
+    const bool advance = (io->phases & GATO_MPC_ADVANCE) != 0, plan = (io->phases & GATO_MPC_PLAN) != 0;
+    if (advance && io->plant_steps > 0) {
+        if (!(io->steps_per_knot > 0.0)) return fail(GATO_ERR_INVALID, "steps_per_knot must be positive");
+        HIPCHK(hipMemcpyAsync(s->d_mpc_fw, io->plant_wrench, 6 * sizeof(float), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL((mpc_plant_kernel<M>), dim3(1), dim3(64), 0, st, s->d_mpc_x, s->d_mpc_xlast, (const float*)s->d_mpc_best, (const float*)s->d_mpc_fw,
+                           (int)io->plant_steps, io->sim_dt, io->steps_per_knot, s->N);
+    }
+    const bool selecting = plan && io->select && s->B > 1;
+    if (plan) {
+        if (!io->ref_window) return fail(GATO_ERR_INVALID, "ref_window is required for GATO_MPC_PLAN");
+        HIPCHK(hipMemcpyAsync(s->d_mpc_refw, io->ref_window, (size_t)6 * s->N * sizeof(float), hipMemcpyHostToDevice, st));
+        if (io->hyp_world) HIPCHK(hipMemcpyAsync(s->d_mpc_hyp, io->hyp_world, (size_t)6 * s->B * sizeof(float), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL((mpc_prepare_kernel<M>), dim3(s->B), dim3(256), 0, st, s->d_xu_own, s->d_xs_own, s->d_ref_own, s->bf.f_ext, (const float*)s->d_mpc_best,
+                           (const float*)s->d_mpc_x, (const float*)s->d_mpc_refw, io->hyp_world ? (const float*)s->d_mpc_hyp : (const float*)nullptr, s->N, s->traj);
+        // reset_rho ahead of every solve (mpc_controller.py:229)
+        HIPCHK(hipMemcpyAsync(s->bf.rho, s->d_rho_init, s->B * sizeof(float), hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipMemcpyAsync(s->bf.drho, s->d_drho_init, s->B * sizeof(float), hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipEventRecord(s->mpc_ev0, st));
+        const int rc = solve_impl<M>(s, s->d_xu_own, s->p.dt, s->d_xs_own, s->d_ref_own, st);
+        if (rc != GATO_OK) return rc;
+        HIPCHK(hipEventRecord(s->mpc_ev1, st));
+        if (selecting) {
+            // evaluate_best_trajectory (mpc_controller.py:294-309): the PREVIOUS state and the previous best trajectory's first control under
+            // every hypothesis against the state just measured
+            uint32_t* cnt = reinterpret_cast<uint32_t*>(s->d_sel_best + 1);
+            HIPCHK(hipMemsetAsync(cnt, 0, sizeof(uint32_t), st));
+            hipLaunchKernelGGL((select_best_kernel<M>), dim3(cdiv(s->B, 256)), dim3(256), 0, st, s->d_sim_out, s->d_sel_err, s->d_sel_best, cnt,
+                               (const float*)s->d_mpc_xlast, (const float*)(s->d_mpc_best + s->nx), (const float*)s->d_mpc_x, (const float*)s->bf.f_ext, s->B,
+                               io->select_dt);
+        } else {
+            HIPCHK(hipMemsetAsync(s->d_sel_best, 0, sizeof(int32_t), st));
+        }
+        hipLaunchKernelGGL(mpc_take_best_kernel, dim3(cdiv(s->traj, 256)), dim3(256), 0, st, s->d_mpc_best, (const float*)s->d_xu_own, (const int32_t*)s->d_sel_best,
+                           s->traj, s->B);
+    }
+    hipLaunchKernelGGL((mpc_report_kernel<M>), dim3(1), dim3(64), 0, st, s->d_mpc_rec, (const float*)s->d_mpc_x, plan ? (const int32_t*)s->d_sel_best : (const int32_t*)nullptr);
+    HIPCHK(hipGetLastError());
+    float rec[20];
+    HIPCHK(hipMemcpyAsync(rec, s->d_mpc_rec, (size_t)(s->nx + 4) * sizeof(float), hipMemcpyDeviceToHost, st));
+    if (selecting && io->errors) HIPCHK(hipMemcpyAsync(io->errors, s->d_sel_err, (size_t)s->B * sizeof(float), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    for (int i = 0; i < s->nx; i++) io->x[i] = rec[i];
+    for (int i = 0; i < 3; i++) io->ee[i] = rec[s->nx + i];
+    io->best = plan ? (int32_t)rec[s->nx + 3] : 0;
+    io->solve_us = 0.0;
+    if (plan) {
+        f32_t ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, s->mpc_ev0, s->mpc_ev1));
+        io->solve_us = (double)ms * 1e3;
+    }
+    if (!selecting && io->errors)
+        for (int b = 0; b < s->B; b++) io->errors[b] = 0;
+    return GATO_OK;
+}
+extern "C" int gato_mpc_step(GatoSolver* s, GatoMpcStep* io)
+{
+    if (!s || !io) return fail(GATO_ERR_INVALID, "null argument");
+    if (!s->mpc_begun) return fail(GATO_ERR_INVALID, "gato_mpc_begin has not been called on this solver");
+    if (!(io->phases & (GATO_MPC_ADVANCE | GATO_MPC_PLAN))) return fail(GATO_ERR_INVALID, "phases: GATO_MPC_ADVANCE and / or GATO_MPC_PLAN");
+    if (io->plant_steps < 0) return fail(GATO_ERR_INVALID, "plant_steps must not be negative");
+    GUARD(s);
+    int rc = sync_last(s);
+    if (rc) return rc;
+    return s->plant == GATO_PLANT_INDY7 ? mpc_step_impl<Indy7>(s, io) : mpc_step_impl<Iiwa14>(s, io);
+}
+extern "C" int gato_mpc_get_best(GatoSolver* s, float* xu_best)
+{
+    if (!s || !xu_best) return fail(GATO_ERR_INVALID, "null argument");
+    if (!s->mpc_begun) return fail(GATO_ERR_INVALID, "gato_mpc_begin has not been called on this solver");
+    GUARD(s);
+    int rc = sync_last(s);
+    if (rc) return rc;
+    HIPCHK(hipMemcpy(xu_best, s->d_mpc_best, (size_t)s->traj * sizeof(float), hipMemcpyDeviceToHost));
     return GATO_OK;
 }
 

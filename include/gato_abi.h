@@ -139,6 +139,39 @@ int gato_select_best(GatoSolver* s, const gato_real* x_last, const gato_real* u_
 int gato_select_best_device(GatoSolver* s, const gato_real* d_x_last, const gato_real* d_u_last, const gato_real* d_x_meas, gato_real dt, int32_t* d_best,
                             gato_real* d_errors, void* stream);
 
+/* ---- MPC session: the closed loop of python/bsqp/mpc_controller.py:196-242 with its state resident on the device ------------------
+ * The reference's MPC step is host numpy between four solver calls (rk4 plant in pinocchio, window slide, reset_rho, solve, sim_forward +
+ * argmin, broadcast of the best row).  Here the measured state x, the best trajectory and the batch iterates live on the device and ONE
+ * call per MPC step enqueues everything on the solver's stream: plant RK4 over the measured interval (controls read from the best
+ * trajectory by knot index) -> every row := best trajectory with first state := x, x_s := x, reference window and wrench hypotheses
+ * (world frame -> last joint frame, mpc_controller.py:311-338) -> reset_rho -> BSQP::solve -> hypothesis selection (:294-309) -> best row.
+ * The host sends the reference window and the hypotheses and reads back {x, end effector, best index, selection errors, solve time}. */
+#define GATO_MPC_ADVANCE 1 /* the plant: `plant_steps` RK4 steps of size sim_dt from the session's state */
+#define GATO_MPC_PLAN 2    /* prepare + reset_rho + solve + selection + take the best row */
+typedef struct GatoMpcStep {
+    /* in */
+    int32_t phases;          /* GATO_MPC_ADVANCE | GATO_MPC_PLAN (a goal-driven loop decides between the two; figure-8 tracking does both at once) */
+    int32_t plant_steps;     /* RK4 steps of the plant (mpc_controller.py:199-218: int(interval / sim_dt), + 1 when the remainders add up) */
+    gato_real sim_dt;
+    double steps_per_knot;   /* dt / sim_dt in double: step i is driven by the control of knot min(int(i / steps_per_knot), N - 1) */
+    gato_real plant_wrench[6];   /* the disturbance actually acting on the last link, spatial [angular; linear], link frame */
+    const gato_real* ref_window; /* [N][6] host: the reference of the N knots (PLAN) */
+    const gato_real* hyp_world;  /* [B][6] host: world-frame wrench hypotheses (linear, angular), or NULL: the stored wrenches stay (PLAN) */
+    int32_t select;          /* != 0: hypothesis selection over the batch (mpc_controller.py:294-309); 0: row 0 is the best */
+    gato_real select_dt;     /* the interval the selection integrates over */
+    /* out */
+    gato_real x[16];         /* the session's state after ADVANCE (nx used) */
+    gato_real ee[3];         /* end-effector position at x */
+    int32_t best;            /* selected row */
+    double solve_us;         /* device time of the SQP solve (hipEvents around its launches); 0 without PLAN */
+    gato_real* errors;       /* [B] host or NULL: the selection's per-hypothesis errors */
+} GatoMpcStep;
+/* state := x0 ([nx] host); every row and the best trajectory := warm start (x0 over the knots, zero controls: common.py:93-99); reset_dual */
+int gato_mpc_begin(GatoSolver* s, const gato_real* x0);
+int gato_mpc_step(GatoSolver* s, GatoMpcStep* io);
+/* the session's best trajectory ([TRAJ] host) */
+int gato_mpc_get_best(GatoSolver* s, gato_real* xu_best);
+
 /* The plant of the closed MPC loop (python/bsqp/common.py:49-91 `rk4` over pinocchio's aba, stepped at 1 kHz by
  * mpc_controller.py:199-218), on the library's own forward dynamics: nsteps RK4 steps of size sim_dt from x ([nx], host, updated in
  * place) with control u_seq[step] ([nsteps][nu], host) under the constant spatial wrench f_ext6 = [angular; linear] acting on the

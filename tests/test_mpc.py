@@ -82,6 +82,99 @@ def test_plant_rk4_against_numpy_rk4_over_the_oracle_dynamics(plant):
     np.testing.assert_allclose(x, np.concatenate([q, v]), rtol=2e-5, atol=2e-6)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("plant,N,B", [("indy7", 16, 8), ("iiwa14", 8, 5)])
+def test_mpc_session_step_equals_the_separate_calls(plant, N, B):
+    """gato_mpc_step (plant -> prepare -> reset_rho -> solve -> selection -> best row, device-resident, one call) against the same step
+    assembled from the separate entry points the way the reference's loop does it (mpc_controller.py:196-242): plant_rk4 with the controls
+    picked by knot index, rows := best with the measured first state, reset_rho, solve, select_best, best row -- bit for bit over three steps."""
+    from gato_amd._lib import NativeSolver
+    from oracle import oracle as O
+    dt, sim_dt = 0.01, 0.001
+    p = dict(DEFAULT_SOLVER_PARAMS, max_sqp_iters=2)
+    nq = 6 if plant == "indy7" else 7
+    nx, nu, ks = 2 * nq, nq, 3 * nq
+    rng = np.random.default_rng(5)
+    x0 = np.concatenate([(INDY7_START_CONFIGS["ready"] if plant == "indy7" else rng.uniform(-0.4, 0.4, nq)), np.zeros(nq)]).astype(np.float32)
+    fext = rng.normal(0, 3.0, (B, 6)).astype(np.float32)            # stored wrench hypotheses (hyp_world = None keeps them)
+    wrench = np.array([0.2, -0.1, 0.3, 2.0, -4.0, 6.0], np.float32)  # what really acts on the plant, [angular; linear]
+    ses, man = NativeSolver(plant, N, B, dt=dt, **p), NativeSolver(plant, N, B, dt=dt, **p)
+    for s in (ses, man):
+        s.set_f_ext_batch(fext)
+    e0 = O.ee(plant, x0[:nq])[0]
+    windows = [np.tile(np.concatenate([e0 + np.array([0.02 * (i + 1), -0.01 * i, 0.015 * i], np.float32), np.zeros(3, np.float32)]), (N, 1)) for i in range(4)]
+    # session: warm-up plan, then three fused steps
+    ses.mpc_begin(x0)
+    ses.mpc_step(advance=False, plan=True, ref_window=windows[0])
+    # by hand
+    xu = np.zeros((B, ks * N - nu), np.float32)
+    for k in range(N):
+        xu[:, k * ks: k * ks + nx] = x0
+    man.reset_dual()
+    r = man.solve(xu, dt, np.tile(x0, (B, 1)), np.tile(windows[0].reshape(-1), (B, 1)))
+    best_row = r["XU"][0].copy()
+    np.testing.assert_array_equal(ses.mpc_best(), best_row)
+    x = x0.copy()
+    for i, nsteps in enumerate((10, 7, 23)):
+        out = ses.mpc_step(advance=True, plan=True, plant_steps=nsteps, sim_dt=sim_dt, steps_per_knot=dt / sim_dt, plant_wrench=wrench,
+                           ref_window=windows[i + 1], select=True, select_dt=nsteps * sim_dt)
+        idx = [min(int(j / (dt / sim_dt)), N - 1) for j in range(nsteps)]
+        useq = np.stack([best_row[nx + ks * k: nx + ks * k + nu] for k in idx])
+        x_last, u_last = x.copy(), best_row[nx: nx + nu].copy()
+        x = man.plant_rk4(x, useq, wrench, sim_dt)
+        rows = np.tile(best_row, (B, 1))
+        rows[:, :nx] = x
+        man.reset_rho()
+        r = man.solve(rows, dt, np.tile(x, (B, 1)), np.tile(windows[i + 1].reshape(-1), (B, 1)))
+        best, err = man.select_best(x_last, u_last, x, nsteps * sim_dt)
+        best_row = r["XU"][best].copy()
+        np.testing.assert_array_equal(out["x"], x)
+        assert out["best"] == best
+        np.testing.assert_array_equal(out["errors"], err)
+        np.testing.assert_array_equal(ses.mpc_best(), best_row)
+        np.testing.assert_allclose(out["ee"], O.ee(plant, x[:nq])[0], atol=2e-6)
+        assert out["solve_us"] > 0
+    # the two-call form of a step (advance, decide on the host, plan) is the same step
+    two = NativeSolver(plant, N, B, dt=dt, **p)
+    two.set_f_ext_batch(fext)
+    two.mpc_begin(x0)
+    two.mpc_step(advance=False, plan=True, ref_window=windows[0])
+    a = two.mpc_step(advance=True, plan=False, plant_steps=10, sim_dt=sim_dt, steps_per_knot=dt / sim_dt, plant_wrench=wrench)
+    b = two.mpc_step(advance=False, plan=True, ref_window=windows[1], select=True, select_dt=10 * sim_dt)
+    one = NativeSolver(plant, N, B, dt=dt, **p)
+    one.set_f_ext_batch(fext)
+    one.mpc_begin(x0)
+    one.mpc_step(advance=False, plan=True, ref_window=windows[0])
+    c = one.mpc_step(advance=True, plan=True, plant_steps=10, sim_dt=sim_dt, steps_per_knot=dt / sim_dt, plant_wrench=wrench, ref_window=windows[1], select=True,
+                     select_dt=10 * sim_dt)
+    np.testing.assert_array_equal(a["x"], c["x"])
+    assert b["best"] == c["best"]
+    np.testing.assert_array_equal(two.mpc_best(), one.mpc_best())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("plant", ["indy7", "iiwa14"])
+def test_session_moves_the_hypotheses_into_the_last_joint_frame(plant):
+    """the device form of transform_force_to_gato_frame (kernels.hpp:force_to_gato_frame, fp32) against the host formula over float64
+    placements (mpc_controller.py:311-338): the wrenches the session stores for the solve"""
+    from gato_amd._lib import NativeSolver, fk_placements
+    from gato_amd.bsqp.mpc_controller import MPC_GATO
+    N, B = 8, 6
+    nq = 6 if plant == "indy7" else 7
+    rng = np.random.default_rng(8)
+    x0 = np.concatenate([rng.uniform(-1.2, 1.2, nq), np.zeros(nq)]).astype(np.float32)
+    hyp = rng.normal(0, 8.0, (B, 6)).astype(np.float32)
+    s = NativeSolver(plant, N, B, dt=0.01, **dict(DEFAULT_SOLVER_PARAMS, max_sqp_iters=1))
+    s.mpc_begin(x0)
+    s.mpc_step(advance=False, plan=True, ref_window=np.zeros((N, 6), np.float32), hyp_world=hyp)
+    got = s.read("f_ext").reshape(B, 6)
+    pl = fk_placements(plant, x0[:nq])
+    want = np.stack([MPC_GATO.transform_force_to_gato_frame(None, x0[:nq], h, placements=pl) for h in hyp])
+    np.testing.assert_allclose(got, want, rtol=0, atol=2e-5 * np.abs(want).max())
+    with pytest.raises(Exception):
+        NativeSolver(plant, N, B, dt=0.01).mpc_step(advance=True, plan=False, plant_steps=1)   # no session begun on this handle
+
+
 def _x_start():
     return np.concatenate([INDY7_START_CONFIGS["ready"], np.zeros(6)])
 

@@ -41,9 +41,11 @@ def main():
             # B in {2} cannot build the force estimator (it needs > 3 hypotheses, force_estimator.py:8): like the reference's benchmark
             # (benchmark_fig8.py passes no disturbance) the batch then carries identical zero-force hypotheses
             _, st = mpc.run_mpc_fig8(x0, fig8, sim_dt=0.001, sim_time=a.sim_time, solve_time_override=0.002, verbose=False)
-            t = np.asarray(st["solve_times"])
+            t = np.asarray(st["solve_times"])              # device time of the SQP solve inside the session call (hipEvents)
+            w = 1e3 * np.asarray(mpc.step_wall_s[1:])      # host wall time of the WHOLE step call: transfers in, plant, prepare, solve, selection, read-back
             pub = PUBLISHED.get(N, [None] * 10)
             r = dict(knots=N, batch=B, steps=int(t.size), mean_ms=float(t.mean()), median_ms=float(np.median(t)), p95_ms=float(np.percentile(t, 95)),
+                     step_wall_mean_ms=float(w.mean()), step_wall_median_ms=float(np.median(w)),
                      mean_goal_dist=float(np.mean(st["goal_distances"])), published_ms=pub[i] if i < len(pub) else None)
             rows.append(r)
             print(json.dumps(r), flush=True)
