@@ -21,6 +21,7 @@ SYMBOLS = [
     "gato_synchronize", "gato_sim_forward_device", "gato_select_best", "gato_select_best_device",
     "gato_plant_rk4", "gato_fk_placements", "gato_set_linear_solver", "gato_set_graph_mode",
     "gato_mpc_begin", "gato_mpc_step", "gato_mpc_get_best",
+    "gato_comm_unique_id", "gato_comm_init", "gato_comm_destroy", "gato_gather_results", "gato_debug_set_remote_solved",
 ]
 
 
@@ -82,6 +83,11 @@ def load(f64=False):
     L.gato_mpc_begin.argtypes = [vp, fp]
     L.gato_mpc_step.argtypes = [vp, C.POINTER(L._MPC)]
     L.gato_mpc_get_best.argtypes = [vp, fp]
+    L.gato_comm_unique_id.argtypes = [C.c_char_p]
+    L.gato_comm_init.argtypes = [vp, C.c_char_p, C.c_int, C.c_int, C.c_int64]
+    L.gato_comm_destroy.argtypes = [vp]
+    L.gato_gather_results.argtypes = [vp, vp, vp, C.c_uint64, vp]
+    L.gato_debug_set_remote_solved.argtypes = [vp, C.POINTER(C.c_uint32), C.c_int, C.c_int64]
     L.gato_default_params.argtypes = [C.POINTER(PT)]
     L.gato_default_params.restype = None
     L.gato_dims.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
@@ -341,6 +347,31 @@ class NativeSolver:
         out = np.zeros(self.traj, self.dtype)
         self._chk(self.L.gato_mpc_get_best(self.h, self._p(out)))
         return out
+
+    # ---- one batch sharded over the GPUs of a node (gato_comm_*): RCCL inside the library, no torch type in sight ----
+    @staticmethod
+    def comm_unique_id(f64=False):
+        """128 bytes from ncclGetUniqueId: rank 0 creates them, every rank passes them to comm_init"""
+        L = load(f64)
+        buf = C.create_string_buffer(128)
+        _chk(L.gato_comm_unique_id(buf), L)
+        return buf.raw
+
+    def comm_init(self, unique_id, world_size, rank):
+        """collective over all ranks: this solver becomes shard `rank` of a batch of world_size x B trajectories"""
+        self._chk(self.L.gato_comm_init(self.h, C.c_char_p(bytes(unique_id)), int(world_size), int(rank), int(world_size) * self.B))
+
+    def comm_destroy(self):
+        self._chk(self.L.gato_comm_destroy(self.h))
+
+    def gather_results(self, d_local, d_all, count, stream=0):
+        """ncclAllGather of `count` reals per rank (raw device pointers), asynchronous on `stream`"""
+        self._chk(self.L.gato_gather_results(self.h, C.c_void_p(d_local), C.c_void_p(d_all), int(count), C.c_void_p(stream)))
+
+    def debug_set_remote_solved(self, per_iter, global_batch):
+        """test hook: the other shards' solved counts per SQP iteration (no communicator); global_batch = 0 ends it"""
+        a = np.ascontiguousarray(per_iter, dtype=np.uint32)
+        self._chk(self.L.gato_debug_set_remote_solved(self.h, a.ctypes.data_as(C.POINTER(C.c_uint32)), int(a.size), int(global_batch)))
 
     def synchronize(self):
         self._chk(self.L.gato_synchronize(self.h))

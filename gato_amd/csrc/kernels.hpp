@@ -74,7 +74,9 @@ struct Buffers {
     // per-iteration stats [max_iters][B]
     int32_t* st_pcg_iters; float *st_min_merit, *st_step;
     Ctrl* ctrl;
-    uint32_t* num_solved;  // [max_iters]: trajectories counted as solved after outer iteration i (bsqp.cuh:142-163)
+    uint32_t* num_solved;  // [max_iters]: trajectories counted as solved after outer iteration i (bsqp.cuh:142-163) -- over the WHOLE batch: what
+                           // the exit rule reads.  On a sharded batch (gato_comm_init) the sum over the ranks of ...
+    uint32_t* num_solved_w;  // ... this rank's own count, which the PCG kernels add to (the same array on a single GPU)
 };
 
 #define GATO_DEV_EARLY __device__ __forceinline__
@@ -1457,7 +1459,7 @@ __global__ __launch_bounds__(MAXT) void pcg_kernel(Buffers bf, int N, int B, uin
         bf.st_pcg_iters[(size_t)sqp_iter * B + b] = (int32_t)iters;
         int conv = skip ? 1 : 0;
         if (iters == 0) { conv = 1; bf.converged[b] = 1; }  // bsqp.cuh:153-156 (kkt_tol is unused there)
-        if (conv) atomicAdd(&bf.num_solved[sqp_iter], 1u);
+        if (conv) atomicAdd(&bf.num_solved_w[sqp_iter], 1u);
     }
 }
 
@@ -2032,7 +2034,7 @@ __global__ __launch_bounds__(MAXT) void pcgc_kernel(Buffers bf, int N, int B, ui
         bf.st_pcg_iters[(size_t)sqp_iter * B + b] = (int32_t)iters;
         int conv = skip ? 1 : 0;
         if (iters == 0) { conv = 1; bf.converged[b] = 1; }  // bsqp.cuh:153-156 (kkt_tol is unused there)
-        if (conv) atomicAdd(&bf.num_solved[sqp_iter], 1u);
+        if (conv) atomicAdd(&bf.num_solved_w[sqp_iter], 1u);
     }
 }
 
@@ -2326,7 +2328,7 @@ __global__ __launch_bounds__(MAXT, 2) void pcgs_kernel(Buffers bf, int N, int B,
         bf.st_pcg_iters[(size_t)sqp_iter * B + b] = (int32_t)iters;
         int conv = skip ? 1 : 0;
         if (iters == 0) { conv = 1; bf.converged[b] = 1; }  // bsqp.cuh:153-156 (kkt_tol is unused there)
-        if (conv) atomicAdd(&bf.num_solved[sqp_iter], 1u);
+        if (conv) atomicAdd(&bf.num_solved_w[sqp_iter], 1u);
     }
 }
 
@@ -2509,7 +2511,7 @@ __global__ __launch_bounds__(64) void btd_direct_kernel(Buffers bf, int N, int B
         const uint32_t it = skip ? 0u : 1u;
         bf.pcg_iters[b] = it;
         bf.st_pcg_iters[(size_t)sqp_iter * B + b] = (int32_t)it;
-        if (skip) atomicAdd(&bf.num_solved[sqp_iter], 1u);
+        if (skip) atomicAdd(&bf.num_solved_w[sqp_iter], 1u);
     }
 }
 
@@ -3041,6 +3043,12 @@ __global__ __launch_bounds__(256) void mpc_prepare_kernel(float* __restrict__ xu
 #pragma unroll
         for (int i = 0; i < 6; i++) f_ext[6 * b + i] = o[i];
     }
+}
+
+// sharded batch without a communicator (tests: gato_debug_set_remote_solved): the other shards' solved count of this iteration is given
+__global__ void add_remote_solved_kernel(uint32_t* __restrict__ global, const uint32_t* __restrict__ local, const uint32_t* __restrict__ remote, int it)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) global[it] = local[it] + remote[it];
 }
 
 // best trajectory := row *best of the batch (the winner of select_best_kernel; row 0 without a selection)

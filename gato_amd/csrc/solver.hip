@@ -4,6 +4,9 @@
 // (python/bindings.cu).  One solve = a fixed sequence of kernel launches on one HIP stream with NO host round trip: the
 // convergence bookkeeping and the solve_ratio early exit of bsqp.cuh:137-176 run on the device (Ctrl / num_solved).
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>   // types and enums only: the library is bound at run time (gato_comm_init), a single-GPU host does not need it
+
+#include <dlfcn.h>
 
 #include <chrono>
 #include <cmath>
@@ -88,6 +91,12 @@ struct GatoSolver {
     float *d_mpc_x, *d_mpc_xlast, *d_mpc_best, *d_mpc_refw, *d_mpc_hyp, *d_mpc_fw, *d_mpc_rec;
     hipEvent_t mpc_ev0, mpc_ev1;
     bool mpc_begun = false;
+    // sharded batch (gato_comm_init): this solver holds rows [rank B, (rank + 1) B) of a batch of global_batch trajectories
+    void* comm = nullptr;              // ncclComm_t
+    int world = 1, rank = 0;
+    long global_batch = 0;             // 0: not sharded
+    uint32_t* d_ns_local = nullptr;    // this rank's own counts (in the per-solve slab)
+    uint32_t* d_ns_remote = nullptr;   // test hook: the other shards' solved counts per iteration (gato_debug_set_remote_solved)
     size_t plant_cap;
     uint32_t max_iters_alloc;
     Buffers bf;
@@ -178,7 +187,8 @@ static int create_impl(GatoSolver* s, int plant, int N, int B, const GatoParams*
         // everything a solve zeroes first (bsqp.cuh:112-114 + the device-side loop control) lives in ONE slab: one memset per solve
         auto up = [](size_t n) { return (n + 63) & ~(size_t)63; };  // 256-byte granules, in 4-byte words
         const size_t o_dz = 0, o_pi = up((size_t)B * s->traj), o_cv = o_pi + up(B), o_ct = o_cv + up(B), o_ns = o_ct + up(sizeof(Ctrl) / 4);
-        s->zero_words = o_ns + up(s->max_iters_alloc);
+        const size_t o_nsl = o_ns + up(s->max_iters_alloc);   // this rank's own solved counts (sharded batch)
+        s->zero_words = o_nsl + up(s->max_iters_alloc);
         float* slab = nullptr;
         DA(slab, s->zero_words);
         s->zero_slab = slab;
@@ -187,6 +197,8 @@ static int create_impl(GatoSolver* s, int plant, int N, int B, const GatoParams*
         bf.converged = reinterpret_cast<int32_t*>(slab + o_cv);
         bf.ctrl = reinterpret_cast<Ctrl*>(slab + o_ct);
         bf.num_solved = reinterpret_cast<uint32_t*>(slab + o_ns);
+        bf.num_solved_w = bf.num_solved;   // one GPU: the count the exit rule reads is the one the PCG kernels add to
+        s->d_ns_local = reinterpret_cast<uint32_t*>(slab + o_nsl);
     }
     DA(bf.merit, (size_t)B * NUM_ALPHAS); DA(bf.merit_cur, B); DA(bf.step, B); DA(s->d_order, B);
     DA(bf.st_pcg_iters, (size_t)s->max_iters_alloc * B); DA(bf.st_min_merit, (size_t)s->max_iters_alloc * B);
@@ -257,6 +269,7 @@ extern "C" int gato_destroy(GatoSolver* s)
     if (!s) return GATO_OK;
     GUARD(s);
     if (s->last_stream_valid) (void)hipStreamSynchronize(s->last_stream);
+    if (s->comm) (void)gato_comm_destroy(s);
     if (s->d_ee_q) (void)hipFree(s->d_ee_q);
     if (s->d_ee_out) (void)hipFree(s->d_ee_out);
     if (s->d_plant) (void)hipFree(s->d_plant);
@@ -272,12 +285,14 @@ extern "C" int gato_destroy(GatoSolver* s)
 
 // ---- launches ---------------------------------------------------------------------------------------------------------
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+// num_solved >= BatchSize * solve_ratio (bsqp.cuh:165), BatchSize = the WHOLE batch when it is sharded over ranks
+static inline float exit_threshold(const GatoSolver* s) { return (float)(s->global_batch > 0 ? s->global_batch : (long)s->B) * s->p.solve_ratio; }
 
 // out2 / zero: only for the first launch of a solve (merit of the initial iterate): second copy of the merits, slab to clear
 template<class M> static void launch_merit(GatoSolver* s, hipStream_t st, int na, float dt, int use_dz, int sqp_iter, float* out, float* out2 = nullptr,
                                            float* zero = nullptr, size_t zero_words = 0)
 {
-    const float thresh = (float)s->B * s->p.solve_ratio;
+    const float thresh = exit_threshold(s);
     const long n = (long)s->B * na * s->N;
     if (na == 1)
         hipLaunchKernelGGL((merit_kernel<M, 1>), dim3(cdiv(n, 256)), dim3(256), 0, st, s->bf, s->N, s->B, dt, use_dz, sqp_iter, thresh, out, out2,
@@ -292,7 +307,7 @@ template<class M> static void launch_kkt(GatoSolver* s, hipStream_t st, float dt
     // batch size would make a trajectory's iterates depend on how many neighbours it has.
     constexpr int NT = (M::NQ + 1) / 2 + 1;
     hipLaunchKernelGGL((kkt_kernel<M>), dim3(cdiv((long)s->B * s->N, 64)), dim3(64 * NT), (size_t)64 * 3 * M::NQ * M::NQ * sizeof(float), st, s->bf, s->N,
-                       s->B, dt, sqp_iter, s->p.solve_ratio * (float)s->B, row0, reinterpret_cast<real4*>(clear_slab ? s->zero_slab : nullptr),
+                       s->B, dt, sqp_iter, exit_threshold(s), row0, reinterpret_cast<real4*>(clear_slab ? s->zero_slab : nullptr),
                        clear_slab ? (uint32_t)(s->zero_words / 4) : 0u);
 }
 // ---- the PCG launch plan ------------------------------------------------------------------------------------------------
@@ -557,7 +572,7 @@ static bool step_fused(const GatoSolver* s)
 // first: the first step launch of a solve also forms the merit of the current iterate ((NUM_ALPHAS + 1) N lanes; see merit_in_step)
 template<class M> static void launch_step(GatoSolver* s, hipStream_t st, float dt, int sqp_iter, int last, bool first = false)
 {
-    const float thresh = (float)s->B * s->p.solve_ratio;
+    const float thresh = exit_threshold(s);
     size_t lds = (size_t)(((s->traj + 3) & ~3) + 12 + 16) * sizeof(float);   // the step, 8 + 1 merits, 16 wavefront partials
     const int T = (NUM_ALPHAS + (first ? 1 : 0)) * s->N;
     float* init0 = first ? s->d_merit_init0 : nullptr;
@@ -585,7 +600,7 @@ static bool merit_in_step(const GatoSolver* s, uint32_t iters)
 }
 static void launch_ls(GatoSolver* s, hipStream_t st, int sqp_iter, int last)
 {
-    const float thresh = (float)s->B * s->p.solve_ratio;
+    const float thresh = exit_threshold(s);
     hipLaunchKernelGGL(line_search_kernel, dim3(s->B), dim3(128), 0, st, s->bf, s->traj, s->B, s->adapt_rho, sqp_iter, thresh,
                        (const float*)s->d_drho_init, last);
 }
@@ -602,6 +617,148 @@ static void mark(GatoSolver* s, hipStream_t st, int stage, size_t& ei)
     s->event_stage[ei] = stage;
     (void)hipEventRecord(s->events[ei], st);
     ei++;
+}
+
+// ---- sharded batch: RCCL bound at run time -------------------------------------------------------------------------------------------
+// The solved count is the only thing that couples the trajectories (bsqp.cuh:165); on a batch sharded over the GPUs of a node every rank
+// counts its own rows (Buffers::num_solved_w) and ONE 4-byte ncclAllReduce per SQP iteration, enqueued on the solve's stream between the PCG
+// launch and the step launch, gives every rank the whole batch's count (Buffers::num_solved): the same exit in the same iteration on every
+// rank, for any solve_ratio, with no host round trip.  librccl is opened with dlopen when a communicator is asked for.
+struct Rccl {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+static Rccl g_rccl;
+static int rccl_load()
+{
+    if (g_rccl.lib) return GATO_OK;
+    // a process that already carries an RCCL (PyTorch ships its own) gets THAT one: same soname, and the one HIP runtime both sit on
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void* h = nullptr;
+    for (const char* n : names)
+        if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL)) != nullptr) break;
+    if (!h) return fail(GATO_ERR_INVALID, std::string("librccl.so is not available: ") + dlerror());
+#define SYM(field, name)                                                                              \
+    *reinterpret_cast<void**>(&g_rccl.field) = dlsym(h, name);                                        \
+    if (!g_rccl.field) return fail(GATO_ERR_INVALID, std::string("librccl.so has no symbol ") + name)
+    SYM(GetUniqueId, "ncclGetUniqueId");
+    SYM(CommInitRank, "ncclCommInitRank");
+    SYM(CommDestroy, "ncclCommDestroy");
+    SYM(AllReduce, "ncclAllReduce");
+    SYM(AllGather, "ncclAllGather");
+    SYM(GetErrorString, "ncclGetErrorString");
+#undef SYM
+    g_rccl.lib = h;
+    return GATO_OK;
+}
+#define NCCLCHK(expr)                                                                                                       \
+    do {                                                                                                                    \
+        ncclResult_t r_ = (expr);                                                                                           \
+        if (r_ != ncclSuccess) return fail(GATO_ERR_HIP, std::string(#expr) + ": " + g_rccl.GetErrorString(r_));            \
+    } while (0)
+
+// after the PCG launch of iteration `it`: Buffers::num_solved[it] := the whole batch's count
+static int reduce_solved(GatoSolver* s, hipStream_t st, int it)
+{
+    if (s->comm) {
+        NCCLCHK(g_rccl.AllReduce(s->d_ns_local + it, s->bf.num_solved + it, 1, ncclUint32, ncclSum, (ncclComm_t)s->comm, st));
+    } else if (s->d_ns_remote) {
+        hipLaunchKernelGGL(add_remote_solved_kernel, dim3(1), dim3(64), 0, st, s->bf.num_solved, (const uint32_t*)s->d_ns_local, (const uint32_t*)s->d_ns_remote, it);
+    } else {
+        return fail(GATO_ERR_INVALID, "sharded solver without a communicator");
+    }
+    return GATO_OK;
+}
+static void set_sharded(GatoSolver* s, long global_batch)
+{
+    s->global_batch = global_batch;
+    s->bf.num_solved_w = global_batch > 0 ? s->d_ns_local : s->bf.num_solved;
+}
+
+extern "C" int gato_comm_unique_id(char* out128)
+{
+    if (!out128) return fail(GATO_ERR_INVALID, "null argument");
+    int rc = rccl_load();
+    if (rc) return rc;
+    ncclUniqueId id;
+    NCCLCHK(g_rccl.GetUniqueId(&id));
+    static_assert(sizeof(id) == 128, "ncclUniqueId is 128 bytes");
+    memcpy(out128, &id, sizeof(id));
+    return GATO_OK;
+}
+extern "C" int gato_comm_init(GatoSolver* s, const char* id128, int world_size, int rank, int64_t global_batch)
+{
+    if (!s || !id128) return fail(GATO_ERR_INVALID, "null argument");
+    if (world_size < 1 || rank < 0 || rank >= world_size) return fail(GATO_ERR_INVALID, "rank must lie in [0, world_size)");
+    if (global_batch != (int64_t)world_size * s->B) return fail(GATO_ERR_INVALID, "global_batch must be world_size x the solver's batch (equal shards)");
+    if (s->comm) return fail(GATO_ERR_INVALID, "the solver already has a communicator");
+    GUARD(s);
+    int rc = rccl_load();
+    if (rc) return rc;
+    rc = sync_last(s);
+    if (rc) return rc;
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof(id));
+    ncclComm_t c = nullptr;
+    NCCLCHK(g_rccl.CommInitRank(&c, world_size, id, rank));
+    s->comm = c;
+    s->world = world_size;
+    s->rank = rank;
+    set_sharded(s, (long)global_batch);
+    return GATO_OK;
+}
+extern "C" int gato_comm_destroy(GatoSolver* s)
+{
+    if (!s) return fail(GATO_ERR_INVALID, "null solver");
+    GUARD(s);
+    int rc = sync_last(s);
+    if (rc) return rc;
+    if (s->comm) {
+        NCCLCHK(g_rccl.CommDestroy((ncclComm_t)s->comm));
+        s->comm = nullptr;
+    }
+    s->world = 1;
+    s->rank = 0;
+    if (!s->d_ns_remote) set_sharded(s, 0);
+    return GATO_OK;
+}
+// the ONE collective of a solve's data path: every rank's packed results [count reals] -> [world][count] on every rank
+extern "C" int gato_gather_results(GatoSolver* s, const float* d_local, float* d_all, uint64_t count, void* stream)
+{
+    if (!s || !d_local || !d_all) return fail(GATO_ERR_INVALID, "null argument");
+    if (!s->comm) return fail(GATO_ERR_INVALID, "the solver has no communicator (gato_comm_init)");
+    GUARD(s);
+    NCCLCHK(g_rccl.AllGather(d_local, d_all, (size_t)count, kDouble ? ncclFloat64 : ncclFloat32, (ncclComm_t)s->comm, (hipStream_t)stream));
+    return GATO_OK;
+}
+// TEST HOOK: a shard without a communicator -- the other shards' solved counts per SQP iteration are given (n <= max_sqp_iters entries,
+// the rest 0); global_batch = 0 returns the solver to the unsharded rule
+extern "C" int gato_debug_set_remote_solved(GatoSolver* s, const uint32_t* per_iter, int n, int64_t global_batch)
+{
+    if (!s) return fail(GATO_ERR_INVALID, "null solver");
+    if (s->comm) return fail(GATO_ERR_INVALID, "the solver has a communicator");
+    GUARD(s);
+    int rc = sync_last(s);
+    if (rc) return rc;
+    if (global_batch <= 0) {
+        set_sharded(s, 0);
+        return GATO_OK;
+    }
+    if (!per_iter || n < 0 || (uint32_t)n > s->max_iters_alloc || global_batch < s->B) return fail(GATO_ERR_INVALID, "bad argument");
+    if (!s->d_ns_remote) {
+        rc = dalloc(s, &s->d_ns_remote, s->max_iters_alloc);
+        if (rc) return rc;
+    }
+    std::vector<uint32_t> h(s->max_iters_alloc, 0u);
+    for (int i = 0; i < n; i++) h[i] = per_iter[i];
+    HIPCHK(hipMemcpy(s->d_ns_remote, h.data(), h.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    set_sharded(s, (long)global_batch);
+    return GATO_OK;
 }
 
 template<class M> static int solve_impl(GatoSolver* s, float* d_xu, float dt, const float* d_xs, const float* d_ref, hipStream_t st)
@@ -638,6 +795,10 @@ template<class M> static int solve_impl(GatoSolver* s, float* d_xu, float dt, co
             launch_schur<M>(s, st, dt, false, false, row0);
             mark(s, st, ST_SCHUR, ei);
             launch_pcg<M>(s, st, (int)it);
+        }
+        if (s->global_batch > 0) {
+            const int rc_r = reduce_solved(s, st, (int)it);
+            if (rc_r != GATO_OK) return rc_r;
         }
         mark(s, st, ST_PCG, ei);
         if (step_fused(s)) {
@@ -1251,6 +1412,7 @@ template<class M> static int stage_impl(GatoSolver* s, int stage, float dt, floa
     hipStream_t st = nullptr;
     HIPCHK(hipMemsetAsync(bf.ctrl, 0, sizeof(Ctrl), st));
     HIPCHK(hipMemsetAsync(bf.num_solved, 0, s->max_iters_alloc * sizeof(uint32_t), st));
+    HIPCHK(hipMemsetAsync(s->d_ns_local, 0, s->max_iters_alloc * sizeof(uint32_t), st));
     switch (stage) {
         case 0: launch_merit<M>(s, st, NUM_ALPHAS, dt, 1, 0, bf.merit); break;
         case 1: launch_kkt<M>(s, st, dt, 0); break;

@@ -1,15 +1,17 @@
-"""Multi-GPU layer: a batch of independent trajectories sharded over the ranks of one node.
+"""Multi-GPU layer: one batch of independent trajectories sharded over the ranks of a node.
 
-Trajectories never read each other (only the early-exit count couples them, bsqp.cuh:165), so rank r solves rows
-[r*B_local, (r+1)*B_local) of the global batch with its own solver handle (its own lambda / rho / f_ext slices) and ONE collective
-per solve gathers iterates and merits: rank-local results live in one packed device buffer [B_local*TRAJ | B_local] that the solver
-writes in place, and a single `all_gather_into_tensor` (RCCL over xGMI with backend "nccl"; gloo on CPU for the tests) assembles the
-[world][B_local*TRAJ + B_local] image on every rank -- no host round trip, no per-field collectives.
+Rank r solves rows [r*B_local, (r+1)*B_local) of the global batch with its own solver handle (its own lambda / rho / f_ext slices).  Two things
+cross ranks:
 
-With solve_ratio = 1 (every shipped configuration) the early exit only fires when ALL trajectories of a shard converged; shards then
-stop independently, which changes no iterate of an unconverged trajectory (a converged shard's extra iterations are what the reference
-would also execute while other trajectories are unconverged).  solve_ratio < 1 couples the shards through the solved count -- it
-would need a 4-byte SUM all-reduce per SQP iteration -- and is refused here (`check_sharded_params`), not silently approximated.
+* the SOLVED COUNT of the exit rule (bsqp.cuh:165) -- the only coupling between trajectories.  `connect()` gives the rank's solver a native RCCL
+  communicator (`gato_comm_init`, include/gato_abi.h) and every SQP iteration then carries one 4-byte ncclAllReduce of that count on the solve's
+  stream: every rank takes the exit of the WHOLE batch in the same iteration, for any solve_ratio.  That also covers solve_ratio = 1: a shard
+  whose rows have all converged keeps stepping them while another shard has not (converged trajectories are still moved by the line search,
+  bsqp.cuh:165-171), exactly as the unsharded solver would -- per-shard counting would stop that shard early and make its iterates depend on
+  the world size.  Without a communicator (`check_sharded_params`) only the case where nothing can converge differently is accepted: it is refused.
+* the RESULTS: rank-local results live in ONE packed device buffer [B_local*TRAJ iterates | B_local merits] that the solver writes in place, and
+  ONE all-gather per solve assembles the [world][B_local*TRAJ + B_local] image on every rank -- `gato_gather_results` (ncclAllGather on the
+  solver's communicator) when the solver has one, `torch.distributed.all_gather_into_tensor` otherwise (gloo on CPU for the tests).
 """
 import numpy as np
 
@@ -21,12 +23,24 @@ def shard_bounds(global_batch, world_size, rank):
     return rank * per, (rank + 1) * per
 
 
-def check_sharded_params(solve_ratio, world_size):
-    """Each rank applies the early-exit threshold B*solve_ratio to its LOCAL batch; that equals the unsharded rule only for
-    solve_ratio >= 1 (exit when everything converged)."""
-    if world_size > 1 and float(solve_ratio) < 1.0:
-        raise ValueError("solve_ratio=%g < 1 is not supported on a sharded batch (world size %d): the early exit counts solved trajectories "
-                         "over the whole batch (bsqp.cuh:165)" % (solve_ratio, world_size))
+def check_sharded_params(solve_ratio, world_size, coupled=False):
+    """A sharded solve is exact only when the ranks share the solved count (`coupled`: connect() below, or the oracle's set_shard in the tests).
+    Uncoupled, each rank would apply the exit rule to its local rows: wrong for solve_ratio < 1, and for solve_ratio >= 1 wrong as soon as one
+    shard's rows all converge before another's (that shard would stop stepping its converged rows).  Refused, not approximated."""
+    if world_size > 1 and not coupled:
+        raise ValueError("a batch sharded over %d ranks needs the solved count shared between them (gato_amd.sharding.connect): the exit rule "
+                         "counts solved trajectories over the whole batch (bsqp.cuh:165; solve_ratio=%g)" % (world_size, solve_ratio))
+
+
+def connect(solver, group=None):
+    """Collective over the ranks of `group`: gives `solver` (a gato_amd._lib.NativeSolver on this rank's device) the native RCCL communicator of
+    the sharded batch.  The 128-byte id travels through torch.distributed (any backend); everything after that is RCCL inside the library."""
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    box = [solver.comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    solver.comm_init(box[0], world, rank)
+    return solver
 
 
 class PackedResults:
@@ -47,11 +61,15 @@ class PackedResults:
     def merit(self):    # [B] view the final merits are copied into (device to device)
         return self.local[self.B * self.traj:]
 
-    def all_gather(self, group=None):
-        """the ONE collective of a solve; stream-ordered on the current stream for nccl"""
+    def all_gather(self, group=None, solver=None, stream=0):
+        """the ONE data-path collective of a solve.  solver (connected): ncclAllGather on its communicator, enqueued on `stream` (a raw
+        hipStream_t); otherwise torch.distributed on torch's current stream."""
         if self.world > 1:
-            import torch.distributed as dist
-            dist.all_gather_into_tensor(self.gathered, self.local, group=group)
+            if solver is not None:
+                solver.gather_results(self.local.data_ptr(), self.gathered.data_ptr(), self.n, stream)
+            else:
+                import torch.distributed as dist
+                dist.all_gather_into_tensor(self.gathered, self.local, group=group)
         return self.gathered
 
     def global_xu(self):     # [world*B, TRAJ]
@@ -63,9 +81,12 @@ class PackedResults:
         return g[:, self.B * self.traj:].reshape(self.world * self.B)
 
     def best(self):
-        """(merit, global index) of the best trajectory of the whole sharded batch -- the MPC selection of
-        mpc_controller.py:294-309 needs no second collective: every rank holds all merits after `all_gather`."""
+        """(merit, global index) of the trajectory with the lowest FINAL MERIT of the whole sharded batch -- every rank holds all merits after
+        `all_gather`, so this needs no second collective.  (This is merit-based selection, e.g. for a hyper-parameter sweep; the MPC loop's
+        hypothesis selection is by prediction error, gato_select_best.)  Non-finite merits never win."""
+        import torch
         m = self.global_merit()
+        m = torch.where(torch.isfinite(m), m, torch.full_like(m, float("inf")))
         i = int(m.argmin().item())
         return float(m[i].item()), i
 

@@ -185,6 +185,23 @@ int gato_fk_placements(int plant, const gato_real* q, double* out);
  * pinocchio in the reference (python/bsqp/interface.py:212-214), computed with the solver's own kinematics. */
 int gato_ee_pos(GatoSolver* s, const gato_real* q, int n, gato_real* out);
 
+/* ---- one batch sharded over the GPUs of a node -------------------------------------------------------------------
+ * Rank r owns rows [r B, (r + 1) B) of a batch of world_size x B trajectories, with its own handle on its own device.  The only thing that
+ * couples trajectories is the solved count of the exit rule (bsqp.cuh:165): with a communicator every SQP iteration carries ONE 4-byte
+ * ncclAllReduce of that count on the solve's stream, so every rank takes the exit of the WHOLE batch in the same iteration, for any
+ * solve_ratio (and a shard whose rows have all converged keeps stepping them while others have not, as the unsharded solver would).
+ * RCCL is opened with dlopen here, never linked: a single-GPU host does not need it.
+ *   gato_comm_unique_id   ncclGetUniqueId: 128 bytes rank 0 hands to the others (any transport)
+ *   gato_comm_init        ncclCommInitRank on the solver's device; collective over all ranks; global_batch = world_size x B
+ *   gato_gather_results   ncclAllGather of `count` reals per rank on `stream`: the one data-path collective of a solve (packed iterates + merits) */
+int gato_comm_unique_id(char* out128);
+int gato_comm_init(GatoSolver* s, const char* id128, int world_size, int rank, int64_t global_batch);
+int gato_comm_destroy(GatoSolver* s);
+int gato_gather_results(GatoSolver* s, const gato_real* d_local, gato_real* d_all, uint64_t count, void* stream);
+/* TEST HOOK: a shard of a global_batch-trajectory batch WITHOUT a communicator: the other shards' solved counts per SQP iteration are given
+ * (global_batch = 0 ends it).  Lets a 1-GPU box check the sharded exit rule against the unsharded solve. */
+int gato_debug_set_remote_solved(GatoSolver* s, const uint32_t* per_iter, int n, int64_t global_batch);
+
 /* Debug / test access to a device buffer by name ("xu" = the solver's own copy used by gato_solve / gato_debug_stage):
  * "xu","D","Qq","Qd","Rd","q","r","c","Qqi","Qdi","Rdi","S","Pinv","gamma","lambda","dz","merit","merit_cur","rho","drho", "step".
  * Copies `count` floats to `out`; returns the buffer length in floats through *len when out == NULL.  "S" and "Pinv" are presented in

@@ -60,6 +60,9 @@ typedef struct {
     uint32_t* pcg_iters;
     /* stats of the last solve */
     uint32_t iters_done, ls_done;
+    uint32_t (*shard_reduce)(uint32_t local_count, uint32_t sqp_iter, void* ctx); /* NULL: the batch is whole */
+    void* shard_ctx;
+    long shard_global_batch;
     int32_t* st_pcg_iters;  /* [max_sqp_iters][B] */
     float *st_min_merit, *st_step; /* [max_sqp_iters][B] */
     float *st_merits, *st_merit_before; /* [max_sqp_iters][B][NUM_ALPHAS], [max_sqp_iters][B]: what every line search chose from (tests) */
@@ -1039,7 +1042,14 @@ uint32_t orc_solve(Orc* o, float* xu, float dt, const float* x_s, const float* r
             o->sqp_iters[b] += 1;
             if (o->kkt_converged[b]) num_solved++;
         }
-        if ((float)num_solved >= (float)B * o->p.solve_ratio) break; /* bsqp.cuh:165 */
+        /* bsqp.cuh:165.  A SHARD of a larger batch (orc_set_shard: the oracle standing in for one rank's solver in the multi-process tests)
+         * applies the rule to the whole batch: the count is summed over the ranks by the caller's reduction */
+        float batch = (float)B;
+        if (o->shard_reduce) {
+            num_solved = o->shard_reduce(num_solved, it, o->shard_ctx);
+            batch = (float)o->shard_global_batch;
+        }
+        if ((float)num_solved >= batch * o->p.solve_ratio) break;
         memcpy(o->converged, o->kkt_converged, B * sizeof(int32_t)); /* bsqp.cuh:167 */
         orc_merit(o, NUM_ALPHAS, o->merit, xu, x_s, ref, dt, 0);
         memcpy(o->st_merits + (size_t)it * B * NUM_ALPHAS, o->merit, (size_t)B * NUM_ALPHAS * sizeof(float));
@@ -1084,6 +1094,11 @@ int32_t* orc_ibuf(Orc* o, const char* name)
     if (!strcmp(name, "pcg_iters")) return (int32_t*)o->pcg_iters;
     if (!strcmp(name, "converged")) return o->converged;
     return NULL;
+}
+/* multi-process tests: this solver holds a shard of a batch of global_batch trajectories; reduce(local solved count, iteration) -> the sum over the ranks */
+void orc_set_shard(Orc* o, uint32_t (*reduce)(uint32_t, uint32_t, void*), void* ctx, long global_batch)
+{
+    o->shard_reduce = reduce; o->shard_ctx = ctx; o->shard_global_batch = global_batch;
 }
 uint32_t orc_iters_done(Orc* o) { return o->iters_done; }
 uint32_t orc_ls_done(Orc* o) { return o->ls_done; }

@@ -73,6 +73,8 @@ def lib(f64=False):
         L.orc_merit.argtypes = [C.c_void_p, C.c_int, fp, fp, fp, fp, ft, C.c_int]
         L.orc_line_search.argtypes = [C.c_void_p, fp]
         L.orc_sim_forward.argtypes = [C.c_void_p, fp, fp, fp, ft]
+        L._REDUCE = C.CFUNCTYPE(C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p)
+        L.orc_set_shard.argtypes = [C.c_void_p, L._REDUCE, C.c_void_p, C.c_long]
         L.orc_iters_done.restype = C.c_uint32
         L.orc_iters_done.argtypes = [C.c_void_p]
         L.orc_ls_done.restype = C.c_uint32
@@ -148,6 +150,13 @@ class OracleSolver:
 
     def set_rho_adaptation(self, e):
         self.L.orc_set_rho_adaptation(self.h, int(bool(e)))
+
+    def set_shard(self, reduce, global_batch):
+        """Multi-process tests: this solver holds a shard of a batch of `global_batch` trajectories; `reduce(local_solved_count, sqp_iter)`
+        returns the count over all ranks (the 4-byte all-reduce per SQP iteration of SURVEY 8(e)); the exit rule of bsqp.cuh:165 then sees the
+        whole batch."""
+        self._reduce_cb = self.L._REDUCE(lambda n, it, ctx: int(reduce(int(n), int(it))))   # keep the thunk alive
+        self.L.orc_set_shard(self.h, self._reduce_cb, None, int(global_batch))
 
     # ---- stage access ----
     SHAPES = {"Q": ("N", "nx", "nx"), "A": ("N", "nx", "nx"), "Qinv": ("N", "nx", "nx"), "R": ("N", "nu", "nu"), "Rinv": ("N", "nu", "nu"),

@@ -1,6 +1,8 @@
-"""The N > 1 path on real devices: two ranks over RCCL ("nccl"), each with its own NativeSolver on its own GPU, the packed
-one-collective gather of gato_amd/sharding.py -- the sharded result equals the single-GPU result bit for bit.  Needs two GPUs
-(skipped on the 1-GPU box; the driver's scaling run exercises the same code through bench.py)."""
+"""The N > 1 path on real devices: two ranks, each with its own NativeSolver on its own GPU and the library's own RCCL communicator
+(gato_comm_init: the solved count shared per SQP iteration, the packed one-collective gather) -- the sharded result equals the single-GPU
+result bit for bit.  The two-GPU test is skipped on the 1-GPU box (the driver's scaling run exercises the same code through bench.py); what
+the box CAN run is here too: a one-rank communicator through the same entry points, two ranks sharing the device with the solved counts
+handed over by the test, and the sharded exit rule on a mixed batch against the unsharded solve."""
 import os
 import socket
 
@@ -33,12 +35,16 @@ def _worker(rank, world, port, N, B, q, one_device=False):
     from gato_amd._lib import NativeSolver
     from gato_amd.bsqp.config import DEFAULT_SOLVER_PARAMS
     from gato_amd.bsqp.workloads import fig8_problem
-    from gato_amd.sharding import PackedResults, check_sharded_params, shard_bounds
+    from gato_amd.sharding import PackedResults, check_sharded_params, connect, shard_bounds
     lo, hi = shard_bounds(B, world, rank)
     p = dict(DEFAULT_SOLVER_PARAMS, max_sqp_iters=3)
-    check_sharded_params(p["solve_ratio"], world)
     pr = fig8_problem("indy7", N, hi - lo, batch_offset=lo)
     s = NativeSolver("indy7", N, hi - lo, dt=0.01, **p)          # bound to cuda:rank (the device current at creation)
+    if one_device:   # no RCCL between two ranks on one device: the other shard's solved counts (none converge here) are handed over
+        s.debug_set_remote_solved(np.zeros(3, np.uint32), B)
+    else:
+        connect(s)   # the library's own communicator: ncclAllReduce of the solved count per SQP iteration, ncclAllGather of the results
+    check_sharded_params(p["solve_ratio"], world, coupled=True)
     pk = PackedResults(hi - lo, s.traj, world, dev)
     pk.xu.copy_(torch.from_numpy(pr["xu"]).to(dev))
     xs, ref = torch.from_numpy(pr["x_s"]).to(dev), torch.from_numpy(pr["ref"]).to(dev)
@@ -52,7 +58,7 @@ def _worker(rank, world, port, N, B, q, one_device=False):
         host.all_gather()
         pk = host
     else:
-        pk.all_gather()
+        pk.all_gather(solver=s, stream=st)
         torch.cuda.synchronize()
     if rank == 0:
         q.put((pk.global_xu().cpu().numpy(), pk.global_merit().cpu().numpy(), pk.best()))
@@ -110,3 +116,71 @@ def test_two_ranks_on_one_gpu_sharded_solve_equals_single_batch():
     np.testing.assert_array_equal(xu, ref["XU"])
     np.testing.assert_array_equal(merit, ref["final_merit"])
     assert best[1] == int(np.argmin(ref["final_merit"]))
+
+
+def test_one_rank_communicator_through_the_same_entry_points():
+    """gato_comm_unique_id / gato_comm_init / the per-iteration ncclAllReduce / gato_gather_results with world size 1 -- everything the 8-GPU run
+    calls, on the box's one device: a solver with the communicator gives the bits of one without, the gather returns the packed buffer."""
+    from gato_amd._lib import NativeSolver
+    from gato_amd.bsqp.config import DEFAULT_SOLVER_PARAMS
+    from gato_amd.bsqp.workloads import fig8_problem
+    from gato_amd.sharding import PackedResults
+    N, B = 32, 24
+    p = dict(DEFAULT_SOLVER_PARAMS, max_sqp_iters=3)
+    pr = fig8_problem("indy7", N, B)
+    plain = NativeSolver("indy7", N, B, dt=0.01, **p).solve(pr["xu"], 0.01, pr["x_s"], pr["ref"])
+    s = NativeSolver("indy7", N, B, dt=0.01, **p)
+    uid = NativeSolver.comm_unique_id()
+    assert len(uid) == 128 and any(uid)
+    s.comm_init(uid, 1, 0)
+    r = s.solve(pr["xu"], 0.01, pr["x_s"], pr["ref"])
+    for k in ("XU", "final_merit", "pcg_iters_all", "ls_step_size", "kkt_converged"):
+        np.testing.assert_array_equal(r[k], plain[k], err_msg=k)
+    dev = torch.device("cuda", 0)
+    pk = PackedResults(B, s.traj, 1, dev)
+    pk.xu.copy_(torch.from_numpy(r["XU"]).to(dev))
+    out = torch.zeros_like(pk.local)
+    s.gather_results(pk.local.data_ptr(), out.data_ptr(), pk.n, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert torch.equal(out, pk.local)
+    s.comm_destroy()
+    r2 = s.solve(pr["xu"], 0.01, pr["x_s"], pr["ref"])     # back to the unsharded rule; warm-started duals: a different solve, still finite
+    assert np.all(np.isfinite(r2["XU"]))
+    with pytest.raises(Exception):
+        s.gather_results(pk.local.data_ptr(), out.data_ptr(), pk.n, 0)   # no communicator any more
+
+
+@pytest.mark.parametrize("ratio", [0.5, 1.0])
+def test_sharded_exit_rule_against_the_unsharded_solve(ratio):
+    """bsqp.cuh:165 on a sharded batch, product path: the mixed batch of tests/mixed_batch.py cut in two shards (the first holds every early
+    converger, the second none), each shard a NativeSolver that counts its own rows and is GIVEN the other shard's solved count per SQP
+    iteration (what the ncclAllReduce delivers on two GPUs): both shards exit in the whole batch's iteration and reproduce their rows of the
+    unsharded solve bit for bit -- also with solve_ratio 1, where the converged shard must keep stepping its rows."""
+    from gato_amd._lib import NativeSolver
+    from gato_amd.bsqp.config import DEFAULT_SOLVER_PARAMS
+    from mixed_batch import mixed_problem
+    from oracle import oracle as O
+    N, kinds = 32, "EUPPEUFFFFFF"
+    B, H = len(kinds), 6
+    p = dict(DEFAULT_SOLVER_PARAMS, max_sqp_iters=6, solve_ratio=ratio, pcg_tol=1e-8, max_pcg_iters=1000)
+    ee = lambda pl, q: O.ee(pl, q)[0]  # noqa: E731
+    pr = mixed_problem("indy7", N, kinds=kinds, ee=ee)
+    one = NativeSolver("indy7", N, B, dt=0.01, **p)
+    one.set_f_ext_batch(pr["f_ext"]); one.set_cost_weights_batch(pr["w"])
+    ref = one.solve(pr["xu"], 0.01, pr["x_s"], pr["ref"])
+    solved = np.cumsum(ref["pcg_iters_all"] == 0, axis=0) > 0          # [iteration, row]: counted as solved in that iteration
+    for lo, hi in ((0, H), (H, B)):
+        other = np.r_[0:lo, hi:B]
+        sh = mixed_problem("indy7", N, kinds=kinds, ee=ee, rows=(lo, hi))
+        s = NativeSolver("indy7", N, hi - lo, dt=0.01, **p)
+        s.set_f_ext_batch(sh["f_ext"]); s.set_cost_weights_batch(sh["w"])
+        s.debug_set_remote_solved(solved[:, other].sum(axis=1).astype(np.uint32), B)
+        r = s.solve(sh["xu"], 0.01, sh["x_s"], sh["ref"])
+        assert r["iters_done"] == ref["iters_done"] and r["ls_num_iters"] == ref["ls_num_iters"]
+        for k in ("XU", "final_merit", "kkt_converged", "sqp_iters"):
+            np.testing.assert_array_equal(r[k], ref[k][lo:hi], err_msg=k)
+        np.testing.assert_array_equal(r["pcg_iters_all"], ref["pcg_iters_all"][:, lo:hi])
+    if ratio == 0.5:
+        assert 2 <= ref["iters_done"] < 6
+    else:
+        assert ref["iters_done"] == 6 and solved[4, :H].all() and not solved[5, H:].all()   # per-shard counting would have stopped shard 0 early
