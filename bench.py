@@ -6,8 +6,14 @@
 
 One step = one pass of the hot path over one batch: reset_dual() + reset_rho() + a full `BSQP::solve` (max_sqp_iters = 10, solve_ratio = 1,
 DEFAULT_SOLVER_PARAMS otherwise) on B = 1024 trajectories per GPU, inputs already resident in HBM, plus -- for N > 1 -- the
-RCCL all_gather of iterates and merits over xGMI.  value = sum over ranks of B * iterations / wall time (max over ranks).
-Rank 0 prints ONE JSON line.
+solved count shared per SQP iteration (4-byte ncclAllReduce inside the solve) and the all-gather of iterates and merits over xGMI.
+value = sum over ranks of B * iterations / wall time (max over ranks).  Rank 0 prints ONE JSON line.
+
+    --workload hparam --plant iiwa14 --knots 64 --batch 512     BASELINE config C5 (the hyper-parameter sweep): rank g solves shard g =
+                                                                cost tuple g of the notebook's grid, per-trajectory rho, dt 0.05, mu 1, pcg_tol 1e-3
+For N > 1 the line also carries per_rank_ms (min / median / max of the ranks' own loop times), gather_ms (event-timed on the communication
+stream) and solve_ms_without_gather, so that an efficiency below 1 can be attributed to skew, to the collective, or to RCCL's kernels
+taking CUs from the next solve.
 """
 import argparse
 import json
@@ -95,17 +101,19 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(plant, N, params, dt, sample_b):
+def cpu_baseline(plant, N, params, dt, sample_b, make_problem):
     """The CPU oracle (a C port of the reference's algorithm, oracle/gato_oracle.c) on this box's host cores, bounded sample:
     trajectories are independent, so `cores` single-threaded oracle solvers each take a contiguous slice of the sample (no barriers)."""
     from concurrent.futures import ThreadPoolExecutor
-    from gato_amd.bsqp.workloads import fig8_problem
     from oracle.oracle import OracleSolver
     cores = min(usable_cores(), 128, sample_b)
     per = sample_b // cores
     sample_b = per * cores
-    pr = fig8_problem(plant, N, sample_b)
+    pr = make_problem(sample_b)
     solvers = [OracleSolver(plant, N, per, dt=dt, threads=1, **params) for _ in range(cores)]
+    if "rho" in pr:
+        for i, sv in enumerate(solvers):
+            sv.set_rho_penalty_batch(pr["rho"][i * per:(i + 1) * per], True)
 
     def run(i):
         sl = slice(i * per, (i + 1) * per)
@@ -150,6 +158,9 @@ def main():
     ap.add_argument("--knots", type=int, default=32)
     ap.add_argument("--batch", type=int, default=1024, help="trajectories per GPU")
     ap.add_argument("--sqp-iters", type=int, default=10)
+    ap.add_argument("--workload", default="fig8", choices=["fig8", "hparam"],
+                    help="fig8: figure-8 tracking windows (the headline, C2 / C4); hparam: BASELINE config C5, rank g solves shard g of the sweep")
+    ap.add_argument("--torch-gather", action="store_true", help="N > 1: gather through torch.distributed instead of the library's own communicator")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=1024)
     a = ap.parse_args()
@@ -171,13 +182,57 @@ def main():
 
     from gato_amd._lib import NativeSolver
     from gato_amd.bsqp.config import DEFAULT_SOLVER_PARAMS
-    from gato_amd.bsqp.workloads import fig8_problem
-    plant, N, B, dt = a.plant, a.knots, a.batch, 0.01
-    params = dict(DEFAULT_SOLVER_PARAMS, max_sqp_iters=a.sqp_iters)
-    pr = fig8_problem(plant, N, B, batch_offset=rank * B)          # rank r owns rows [r*B, (r+1)*B) of the global batch
+    from gato_amd.bsqp.workloads import fig8_problem, hparam_problem
+    plant, N, B = a.plant, a.knots, a.batch
+    if a.workload == "hparam":
+        # BASELINE config C5: rank g = shard g of the sweep (cost tuple g, per-trajectory rho, dt 0.05, mu 1, pcg_tol 1e-3)
+        def make_problem(n, shard=rank):
+            return hparam_problem(plant, N, n, shard=shard)
+        pr = make_problem(B)
+        params, dt = dict(pr["params"], max_sqp_iters=a.sqp_iters), pr["dt"]
+        what = ("hyper-parameter sweep (gato_hparam_batch.ipynb): one random goal per trajectory, shard g on rank g = cost tuple g of the grid, "
+                "per-trajectory rho 1e-8..1e1, dt 0.05, mu 1, pcg_tol 1e-3")
+    else:
+        def make_problem(n, offset=rank * B):
+            return fig8_problem(plant, N, n, batch_offset=offset)      # rank r owns rows [r*B, (r+1)*B) of the global batch
+        pr = make_problem(B)
+        params, dt = dict(DEFAULT_SOLVER_PARAMS, max_sqp_iters=a.sqp_iters), 0.01
+        what = "figure-8 end-effector tracking, DEFAULT_SOLVER_PARAMS (max_pcg 200, pcg_tol 1e-4, rho 0.01)"
     solver = NativeSolver(plant, N, B, dt=dt, **params)
-    from gato_amd.sharding import PackedResults, check_sharded_params
-    check_sharded_params(params["solve_ratio"], world)
+    if "rho" in pr:
+        solver.set_rho_penalty_batch(pr["rho"], True)      # also the value reset_rho() goes back to
+    from gato_amd.sharding import PackedResults, check_sharded_params, connect
+    native = False
+    collective = "none"
+    if world > 1:
+        # the library's own communicator (gato_comm_init): the solved count of the exit rule is shared per SQP iteration inside the solve
+        # and the results travel by ncclAllGather on it.  Checked before use: every rank gathers a known pattern; if ANY rank fails the
+        # whole job falls back to torch.distributed for the results (and to per-shard counting, exact here: fig-8 / sweep rows do not converge)
+        ok_t = torch.ones(1, device=dev)
+        try:
+            connect(solver)
+            probe = torch.full((4,), float(rank + 1), device=dev)
+            got = torch.zeros(4 * world, device=dev)
+            solver.gather_results(probe.data_ptr(), got.data_ptr(), 4, torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            want = torch.arange(1, world + 1, device=dev, dtype=torch.float32).repeat_interleave(4)
+            if not torch.equal(got, want):
+                ok_t.zero_()
+        except Exception as e:   # noqa: BLE001
+            print("rank %d: native communicator unavailable (%s)" % (rank, e), file=sys.stderr)
+            ok_t.zero_()
+        dist.all_reduce(ok_t, op=dist.ReduceOp.MIN)
+        native = bool(ok_t.item() > 0) and not a.torch_gather
+        if not bool(ok_t.item() > 0):
+            try:
+                solver.comm_destroy()
+            except Exception:   # noqa: BLE001
+                pass
+        coupled = bool(ok_t.item() > 0)
+        if not coupled:
+            solver.debug_set_remote_solved(np.zeros(1, np.uint32), world * B)   # shards count alone: exact while nothing converges (checked below)
+        check_sharded_params(params["solve_ratio"], world, coupled=True)
+        collective = "ncclAllGather on the library's communicator" if native else "torch.distributed.all_gather_into_tensor"
     xu0 = torch.from_numpy(pr["xu"]).to(dev)
     x_s = torch.from_numpy(pr["x_s"]).to(dev)
     ref = torch.from_numpy(pr["ref"]).to(dev)
@@ -192,7 +247,9 @@ def main():
     used = [False, False]
     count = [0]
 
-    def step():
+    gather_ev = []   # (start, end) events on the communication stream, one pair per gather
+
+    def step(gather=True):
         j = count[0] & 1
         count[0] += 1
         pk = pks[j]
@@ -202,10 +259,14 @@ def main():
         pk.xu.copy_(xu0)
         solver.solve_device(pk.xu.data_ptr(), dt, x_s.data_ptr(), ref.data_ptr(), stream)
         solver.copy_final_merit_device(pk.merit.data_ptr(), stream)
-        if comm is not None:
+        if comm is not None and gather:
             comm.wait_stream(main)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             with torch.cuda.stream(comm):
-                pk.all_gather()                 # iterates + costs: (B x TRAJ + B) fp32 per rank over xGMI
+                e0.record(comm)
+                pk.all_gather(solver=solver if native else None, stream=comm.cuda_stream)   # iterates + costs: (B x TRAJ + B) fp32 per rank over xGMI
+                e1.record(comm)
+            gather_ev.append((e0, e1))
             done[j].record(comm)
             used[j] = True
 
@@ -218,15 +279,37 @@ def main():
         step()
     sync()
     stage_acc = {}
+    gather_ev.clear()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
+    torch.cuda.synchronize()
+    t_own = time.perf_counter() - t0          # this rank's own loop, before it waits for the others
     sync()
     t = time.perf_counter() - t0
+    multi = {}
     if world > 1:
         tt = torch.tensor([t], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         t = float(tt.item())
+        own = [torch.zeros(2, dtype=torch.float64, device=dev) for _ in range(world)]
+        g_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in gather_ev])) if gather_ev else 0.0
+        dist.all_gather(own, torch.tensor([1e3 * t_own / a.steps, g_ms], dtype=torch.float64, device=dev))
+        own = torch.stack(own).cpu().numpy()
+        # the same loop with the gather switched off (untimed for the headline): what the collective and its kernels cost the solves
+        sync()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(main)
+        for _ in range(max(2, a.steps // 4)):
+            step(gather=False)
+        e1.record(main)
+        sync()
+        ng = torch.tensor([e0.elapsed_time(e1) / max(2, a.steps // 4)], dtype=torch.float64, device=dev)
+        dist.all_reduce(ng, op=dist.ReduceOp.MAX)
+        multi = {"collective": collective, "solved_count": "ncclAllReduce per SQP iteration inside the solve" if coupled else "per shard (no communicator)",
+                 "per_rank_ms": {"min": float(own[:, 0].min()), "median": float(np.median(own[:, 0])), "max": float(own[:, 0].max())},
+                 "gather_ms": {"mean_over_ranks": float(own[:, 1].mean()), "max_over_ranks": float(own[:, 1].max())},
+                 "solve_ms_without_gather": float(ng.item())}
 
     st = solver.stats()
     iters = st["iters_done"]
@@ -236,7 +319,10 @@ def main():
     sync()
     stage_acc = solver.stage_times_us()
     solver.set_profiling(False)
-    ok = bool(np.all(np.isfinite(st["final_merit"])) and np.all(st["final_merit"] < st["initial_merit"]))
+    # every trajectory finite and none worse than it started (a sweep row whose rho makes every line search fail keeps its merit: equal)
+    ok = bool(np.all(np.isfinite(st["final_merit"])) and np.all(st["final_merit"] <= st["initial_merit"]) and np.any(st["final_merit"] < st["initial_merit"]))
+    if world > 1 and not coupled:
+        ok = ok and not bool(np.any(st["kkt_converged"]))   # shards that count alone are exact only while nothing converges
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -271,11 +357,12 @@ def main():
         try:
             js = json.load(open(pmc_path))
             pat = {"pcg": "pcg", "kkt": "kkt_kernel", "merit": "step_kernel"}.get(dom, dom)
-            rows = [(k, v) for k, v in js.get("c2", {}).items() if pat in k]
+            section = {("indy7", 32, 1024, "fig8"): "c2", ("iiwa14", 128, 256, "fig8"): "c3", ("iiwa14", 64, 512, "hparam"): "c5"}.get((plant, N, B, a.workload))
+            rows = [(k, v) for k, v in js.get(section, {}).items() if pat in k] if section else []   # counters only of the configuration that ran
             if rows:
                 k, v = max(rows, key=lambda kv: kv[1].get("pct_of_gpu_time", 0.0))
                 traffic = v.get("hbm_bytes")
-                pmc = {"kernel": k, "profiled_build": js.get("build"), "this_build": source_hash(), "build_matches": js.get("build") == source_hash(),
+                pmc = {"section": section, "kernel": k, "profiled_build": js.get("build"), "this_build": source_hash(), "build_matches": js.get("build") == source_hash(),
                        "rocprof_avg_us": v.get("avg_us"), "valu_issue_frac": v.get("valu_issue_frac"), "lds_bank_conflict_frac": v.get("lds_bank_conflict_frac"),
                        "mfma_busy_cycles": v.get("mfma_busy_cycles")}
         except Exception:
@@ -283,15 +370,14 @@ def main():
     hbm = {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_frac, "algorithmic_bytes_per_launch": dom_bytes}
     top = valu if (valu and valu["frac"] >= hbm_frac) else hbm
     line = {
-        "metric": "SQP iterations/sec (whole node), indy7 N=32 batch=1024, 1/2/4/8 MI355X" if (plant, N, B) == ("indy7", 32, 1024)
-                  else "SQP iterations/sec (whole node), %s N=%d batch=%d (not the headline configuration)" % (plant, N, B),
+        "metric": "SQP iterations/sec (whole node), indy7 N=32 batch=1024, 1/2/4/8 MI355X" if (plant, N, B, a.workload) == ("indy7", 32, 1024, "fig8")
+                  else "SQP iterations/sec (whole node), %s N=%d batch=%d %s (not the headline configuration)" % (plant, N, B, a.workload),
         "value": value, "unit": "trajectory-SQP-iterations/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": 1e3 * t / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "%s N=%d batch=%d per GPU (global %d), figure-8 end-effector tracking, %d SQP iterations per solve, "
-                               "DEFAULT_SOLVER_PARAMS (max_pcg 200, pcg_tol 1e-4, rho 0.01), reset_dual+reset_rho per solve"
-                               % (plant, N, B, world * B, iters),
+        "config": {"workload": "%s N=%d batch=%d per GPU (global %d), %s, %d SQP iterations per solve, reset_dual+reset_rho per solve"
+                               % (plant, N, B, world * B, what, iters),
                    "plant": plant, "knot_points": N, "batch_per_gpu": B, "global_batch": world * B, "sqp_iters_per_solve": int(iters),
-                   "mean_pcg_iters": float(st["pcg_iters_all"].mean()), "parallelism": "batch-sharded x%d, one packed all_gather of iterates + merits per solve, overlapped with the next solve" % world},
+                   "mean_pcg_iters": float(st["pcg_iters_all"].mean()), "parallelism": "batch-sharded x%d, solved count shared per SQP iteration, one packed all_gather of iterates + merits per solve, overlapped with the next solve" % world},
         "roofline": {"bound": "valu" if top is valu else "hbm", "kernel": dom, "achieved": top["achieved"], "peak": top["peak"], "unit": top["unit"],
                      "frac": top["frac"], "traffic": traffic, "hbm": hbm, "valu": valu, "pmc": pmc, "avg_launch_us": per_launch_us[dom],
                      "stage_us_per_solve": {k: round(v, 1) for k, v in stage_acc.items()},
@@ -300,8 +386,10 @@ def main():
                                          "hbm_frac": iter_bytes * value / world / 1e9 / HBM_PEAK_GBS}},
         "solution_ok": ok,
     }
+    if multi:
+        line["multi_gpu"] = multi
     if not a.no_cpu_baseline and world == 1:
-        line["cpu_baseline"] = cpu_baseline(plant, N, params, dt, a.cpu_sample)
+        line["cpu_baseline"] = cpu_baseline(plant, N, params, dt, a.cpu_sample, make_problem)
         line["cpu_baseline"]["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
     print(json.dumps(line))
     if world > 1:

@@ -9,8 +9,8 @@ OUT=$ROOT/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 declare -A CMD
 CMD[c2]="$ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline"
-CMD[c3]="$ROOT/tools/gpu_time.py --plant iiwa14 -N 128 -B 256 --reps 3"
-CMD[c5]="$ROOT/tools/gpu_time.py --plant iiwa14 -N 64 -B 512 --reps 3 --c5"
+CMD[c3]="$ROOT/bench.py --plant iiwa14 --knots 128 --batch 256 --steps 5 --warmup 2 --no-cpu-baseline"
+CMD[c5]="$ROOT/bench.py --workload hparam --plant iiwa14 --knots 64 --batch 512 --steps 5 --warmup 2 --no-cpu-baseline"
 for cfg in c2 c3 c5; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_${cfg} -o k -- python3 ${CMD[$cfg]} > $OUT/prof_${TAG}_${cfg}.log 2>&1
 done
