@@ -21,7 +21,7 @@ SYMBOLS = [
     "gato_synchronize", "gato_sim_forward_device", "gato_select_best", "gato_select_best_device",
     "gato_plant_rk4", "gato_fk_placements", "gato_set_linear_solver", "gato_set_graph_mode",
     "gato_mpc_begin", "gato_mpc_step", "gato_mpc_get_best",
-    "gato_comm_unique_id", "gato_comm_init", "gato_comm_destroy", "gato_gather_results", "gato_debug_set_remote_solved",
+    "gato_comm_unique_id", "gato_comm_init", "gato_comm_destroy", "gato_gather_results", "gato_debug_set_remote_solved", "gato_abi_real_size",
 ]
 
 
@@ -125,6 +125,8 @@ def load(f64=False):
     L.gato_sim_forward_device.argtypes = [vp, vp, vp, vp, ft, vp]
     L.gato_last_error.restype = C.c_char_p
     L.gato_version.restype = C.c_char_p
+    if L.gato_abi_real_size() != C.sizeof(ft):
+        raise GatoError("%s carries %d-byte reals, the binding expects %d" % (path, L.gato_abi_real_size(), C.sizeof(ft)))
     _libs[f64] = L
     if not f64:
         _lib = L

@@ -283,6 +283,8 @@ PYBIND11_MODULE(GATO_EXT_NAME, m)
 {
     m.doc() = "MI355X-native batched SQP solver (pybind11 over the C ABI of libgato_hip.so); replaces python/bindings.cu";
     m.attr("version") = gato_version();
+    if (gato_abi_real_size() != (int)sizeof(float))   // `float` is this module's real type (see the top of the file)
+        throw std::runtime_error("the library this extension is linked to carries another real type (-DGATO_DOUBLE goes with libgato_hip_f64.so)");
     // world placements (R [nq,3,3], p [nq,3], float64) of the joint frames from the library's kinematic tables -- pinocchio's
     // data.oMi[1..nq] in MPC_GATO.transform_force_to_gato_frame (mpc_controller.py:311-338); host-only
     m.def("fk_placements", [](const std::string& plant, farray q) {

@@ -4,7 +4,8 @@
 // every `float` that follows this header is the solver's real type, and the same sources compile to libgato_hip_f64.so with the same
 // entry points on double buffers -- the float64 build of the oracle is made the same way (oracle/Makefile).  Vector types, math functions
 // and lane operations go through the aliases and overloads below so that they follow.  The float64 build is the validation mode it is in
-// the reference: it runs the stand-alone kernels only (solver.hip: plan_pcg), every register budget in kernels.hpp being sized for fp32.
+// the reference: it runs the SAME kernel plan as fp32 (fused, pair, symmetric storage ...: solver.hip:plan_pcg has no branch on the real
+// type), and since every register budget in kernels.hpp is sized for 4-byte reals its kernels spill -- correct, several times slower.
 #pragma once
 
 namespace gato {

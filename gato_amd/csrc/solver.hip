@@ -1103,7 +1103,10 @@ extern "C" int gato_select_best_device(GatoSolver* s, const float* d_x_last, con
     if (!s || !d_x_last || !d_u_last || !d_x_meas || !d_best || !d_err) return fail(GATO_ERR_INVALID, "null argument");
     GUARD(s);
     hipStream_t st = (hipStream_t)stream;
+    // one completion counter per handle, cleared on the call's stream ahead of every launch (a launch that faulted, or two calls in flight,
+    // cannot leave a count behind); x_next goes to the solver-owned d_sim_out: the _device entry is single-stream per handle
     uint32_t* cnt = reinterpret_cast<uint32_t*>(s->d_sel_best + 1);
+    HIPCHK(hipMemsetAsync(cnt, 0, sizeof(uint32_t), st));
     if (s->plant == GATO_PLANT_INDY7)
         hipLaunchKernelGGL((select_best_kernel<Indy7>), dim3(cdiv(s->B, 256)), dim3(256), 0, st, s->d_sim_out, d_err, d_best, cnt, d_x_last, d_u_last, d_x_meas,
                            s->bf.f_ext, s->B, dt);
@@ -1465,3 +1468,6 @@ extern "C" int gato_get_stage_times_us(GatoSolver* s, double* out7)
 
 extern "C" const char* gato_last_error(void) { return g_err.c_str(); }
 extern "C" const char* gato_version(void) { return "gato_amd 0.1.0 (gfx950)"; }
+extern "C" int gato_abi_real_size(void) { return (int)sizeof(float); }   // `float` is the real type here (real.hpp)
+static_assert(sizeof(GatoParams) == (kDouble ? 15 * 8 : 15 * 4), "GatoParams: 13 reals + 2 uint32 (padded to reals in the float64 build)");
+static_assert(sizeof(((GatoMpcStep*)nullptr)->x) == 16 * sizeof(float), "GatoMpcStep carries the library's real type");

@@ -159,7 +159,12 @@ class BSQP {
     GatoSolver* handle() { return s_; }
 
   private:
-    void init(int plant, int knot_points, const GatoParams& p) { chk(gato_create(plant, knot_points, (int)BatchSize, &p, &s_)); }
+    void init(int plant, int knot_points, const GatoParams& p)
+    {
+        // the library linked must carry this translation unit's real type (libgato_hip.so: float, libgato_hip_f64.so with -DGATO_DOUBLE: double)
+        if (gato_abi_real_size() != (int)sizeof(T)) throw std::runtime_error("libgato_hip: the linked library's real type is not sizeof(T) -- -DGATO_DOUBLE goes with libgato_hip_f64.so");
+        chk(gato_create(plant, knot_points, (int)BatchSize, &p, &s_));
+    }
     static void chk(int rc)
     {
         if (rc != GATO_OK) throw std::runtime_error(std::string("libgato_hip: ") + gato_last_error());

@@ -9,7 +9,10 @@
  *
  * Real type: `gato_real` = float in libgato_hip.so (the reference's default `typedef float T`, gato/settings.h:7-11); compiled with
  * -DGATO_DOUBLE -- the reference's USE_DOUBLES -- the same sources give libgato_hip_f64.so with the same entry points on double
- * buffers (a validation mode, as in the reference: python/bindings.cu:244-252 registers double classes up to batch 128 only).
+ * buffers.  VALIDATION ONLY, as in the reference (python/bindings.cu:244-252 registers double classes up to batch 128 only): the kernels'
+ * register budgets are sized for 4-byte reals, the float64 build spills and runs several times slower (C3: 104 vs 5.6 ms per solve); it
+ * exists as the arbiter of the fp32 path (it equals the float64 oracle to 1e-9).  A client must be compiled with the same -DGATO_DOUBLE as
+ * the library it links: gato_abi_real_size() returns the library's sizeof(gato_real) for a start-up check (include/bsqp.hpp makes it).
  *
  * Layouts are the reference's (gato/utils/linalg.cuh:545-672), all gato_real, C-contiguous:
  *   xu    [B][TRAJ]      TRAJ = (nx+nu) N - nu, knot = [x_k (nx), u_k (nu)], last knot x only
@@ -219,6 +222,8 @@ int gato_get_stage_times_us(GatoSolver* s, double* out7);
 
 const char* gato_last_error(void);
 const char* gato_version(void);
+/* sizeof(gato_real) of the LIBRARY: 4 for libgato_hip.so, 8 for libgato_hip_f64.so (a client compiled with the other setting must not call it further) */
+int gato_abi_real_size(void);
 
 #ifdef __cplusplus
 }
