@@ -2515,6 +2515,388 @@ __global__ __launch_bounds__(64) void btd_direct_kernel(Buffers bf, int N, int B
     }
 }
 
+// ---- direct solve, parallel over the knots: block cyclic reduction (round 3) ------------------------------------------------------------
+// The sweep above is a chain of N dependent block eliminations (N x ~2.4 us at a lone wavefront's issue rate); PCG at a long horizon is
+// 110-130 iterations of 1.9 us.  Neither uses more than a fraction of one CU when the batch is small -- the MPC case (B = 1..8), where the
+// reference's published N = 128 times were still ahead.  Cyclic reduction has log2(N) levels: at stride s every second active block row
+// j = s-1 + 2 s u is eliminated, its neighbours i = j +- s keep
+//     D_i <- D_i - L_i D_{i-s}^-1 L_i^T - L_{i+s}^T D_{i+s}^-1 L_{i+s},   g_i <- g_i - L_i D_{i-s}^-1 g_{i-s} - L_{i+s}^T D_{i+s}^-1 g_{i+s},
+//     L_i <- - L_i D_{i-s}^-1 L_{i-s}                                      (L_i: the coupling of row i to its LEFT active neighbour)
+// and the system stays symmetric block-tridiagonal over the kept rows (right_i = left_{i+2s}^T), so only left and main blocks exist.  All
+// eliminations of a level are independent: one workgroup of WAVES wavefronts per trajectory deals them to its wavefronts (the 14 x 14 /
+// 12 x 12 algebra of one block row in the sweep's lane = (row, column group) layout, operands through a per-wavefront LDS tile), two
+// workgroup barriers per level.  After log2(N) levels one block row is left; back substitution runs the levels in reverse:
+//     x_j = D_j^-1 (g_j - L_j x_{j-s} - C_j^T x_{j+s}),   C_j = the coupling block L_{j+s} as it was when j was eliminated.
+// -S is symmetric positive definite, every reduced block is a Schur complement of it: no pivoting needed, like the sweep.
+// Storage: S's left / main blocks are overwritten (the system is re-formed every SQP iteration); the P^-1 buffer (unused in this mode)
+// keeps D_j^-1 (left slot) and C_j (main slot) of the eliminated rows; g lives in lambda until x overwrites it.
+template<class M, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void btd_cr_kernel(Buffers bf, int N, int B, int sqp_iter)
+{
+    constexpr int NQ = M::NQ, NX = 2 * NQ, BLK = NX * NX, BROW = 3 * NX * NX;
+    constexpr int CW = (NX + 3) / 4, LD = 20, TOP = 16;   // TOP: active rows from which on the reduction runs out of LDS
+    // per-wavefront operand tiles: 16 rows of LD floats; column c sits at P(c) = 4 (c / CW) + c % CW, so that a lane's CW columns are ONE
+    // aligned 16-byte LDS access (the product loops were 56 ds_read_b32 per 14 x 14 product otherwise) and a whole row is four of them
+    auto P = [](int c) { return 4 * (c / CW) + (c % CW); };
+#ifdef GATO_DOUBLE
+    constexpr bool MFMA = false;   // the validation build keeps the packed-FMA products (and half the wavefronts: its reals are twice as wide)
+    constexpr int NT = 2, TSZ = 16 * LD;
+#else
+    // fp32: the kept rows' five 14 x 14 x 14 (12 x 12 x 12) products run on the matrix cores.  Here ONE wavefront forms ONE product at a
+    // time -- the shape v_mfma_f32_16x16x4_f32 is made for (77 % / 56 % of the tile filled, 4 issues of 32 cycles per product against
+    // ~80 vector instructions) -- unlike the PCG prologue, where a wavefront's lanes work on 16 knots side by side.
+    constexpr bool MFMA = true;
+    constexpr int NT = 4, TSZ = 16 * 17;
+#endif
+    __shared__ __attribute__((aligned(32))) float tiles[WAVES][NT][TSZ];
+    __shared__ float vecs[WAVES][32];
+    extern __shared__ __attribute__((aligned(16))) float top[];   // [L | D | D^-1 | C][TOP][BLK] + g [TOP][NX]: the last log2(TOP) levels
+    if (bf.ctrl->done) return;
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int r = lane >> 2, cq = lane & 3;
+    const int c0 = cq * CW;
+    const bool rowok = r < NX;
+    float* S = bf.S + (size_t)b * N * BROW;
+    float* W = bf.Pinv + (size_t)b * N * BROW;
+    const float* gam = bf.gamma + (size_t)b * (N + 2) * NX;
+    float* g = bf.lambda + (size_t)b * (N + 2) * NX + NX;   // g_k, later x_k, at g + k NX
+    const bool skip = bf.converged[b] != 0;
+
+    if (!skip) {
+        float* tA = tiles[wv][0];
+        float* tB = tiles[wv][1];
+        float* tv = vecs[wv];
+        // Lanes of ONE wavefront hand values to each other through its LDS tiles: a wavefront-scope fence between the stores and the loads
+        // (an s_waitcnt, no barrier).  Without it the loads were seen returning the tile's previous contents (measured: g of the first kept row).
+        auto lds_handoff = [&]() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); };
+        // Two tiers of storage.  While more than TOP block rows are active they live in global memory (L2): 2 N nx^2 floats do not fit
+        // LDS, and with >= one elimination per wavefront the four wavefronts of a SIMD hide each other's load latency.  From TOP active
+        // rows on there are fewer eliminations than wavefronts and every level is ONE task deep: its operands' latency is the level's
+        // duration, so the active rows move to LDS (4 x 16 blocks) and the last log2(TOP) levels and their back substitution run from there.
+        const int s_top = N > TOP ? N / TOP : 1;              // stride from which on the active rows are in LDS
+        int sh = 0;
+        while ((1 << sh) < s_top) sh++;
+        struct Tier { float *L, *D, *Wd, *Wc, *g; int bs, shift; };
+        const Tier glob{S, S + BLK, W, W + BLK, g, BROW, 0};
+        const Tier lds{top, top + TOP * BLK, top + 2 * TOP * BLK, top + 3 * TOP * BLK, top + 4 * TOP * BLK, BLK, sh};
+        auto at = [&](const Tier& T, int i) { return ((i + 1) >> T.shift) - 1; };   // position of block row i in its tier
+
+        // entry (r, c0 + i) of a row-major NX x NX block; the padding to 16 x 16 is `diag` on the diagonal, 0 elsewhere
+        auto load_slice = [&](const float* blk, float* out, float diag) {
+#pragma unroll
+            for (int i = 0; i < CW; i++) {
+                const int c = c0 + i;
+                out[i] = (rowok && c < NX) ? blk[(size_t)r * NX + c] : ((r == c) ? diag : 0.f);
+            }
+        };
+        auto store_slice = [&](float* blk, const float* in) {
+#pragma unroll
+            for (int i = 0; i < CW; i++)
+                if (rowok && c0 + i < NX) blk[(size_t)r * NX + c0 + i] = in[i];
+        };
+        auto tile_put = [&](float* t, const float* sl) {
+            lds_handoff();   // the tile's previous readers are done
+            reinterpret_cast<real4*>(t + r * LD)[cq] = make_real4(sl[0], sl[1], sl[2], CW > 3 ? sl[CW - 1] : 0.f);
+            lds_handoff();
+        };
+        auto tile_row = [&](const float* t, float* row) {      // row r of the tile
+            float w[16];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const real4 v = reinterpret_cast<const real4*>(t + r * LD)[q];
+                w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
+            }
+#pragma unroll
+            for (int j = 0; j < NX; j++) row[j] = w[P(j)];
+        };
+        auto tile_col = [&](const float* t, float* col) {      // column r of the tile = row r of its transpose
+            const int pr = 4 * (r / CW) + (r % CW);
+#pragma unroll
+            for (int j = 0; j < NX; j++) col[j] = t[j * LD + pr];
+        };
+        auto row_x_tile = [&](const float* row, const float* t, float* out) {    // (row . B)(own columns)
+            float o[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < NX; j++) {
+                const real4 v = reinterpret_cast<const real4*>(t + j * LD)[cq];
+                o[0] = __builtin_fmaf(row[j], v.x, o[0]);
+                o[1] = __builtin_fmaf(row[j], v.y, o[1]);
+                o[2] = __builtin_fmaf(row[j], v.z, o[2]);
+                o[3] = __builtin_fmaf(row[j], v.w, o[3]);
+            }
+#pragma unroll
+            for (int i = 0; i < CW; i++) out[i] = o[i];
+        };
+        auto row_x_tileT = [&](const float* row, const float* t, float* out) {   // (row . B^T)(own columns)
+#pragma unroll
+            for (int i = 0; i < CW; i++) {
+                float w[16];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const real4 v = reinterpret_cast<const real4*>(t + (c0 + i) * LD)[q];
+                    w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
+                }
+                float a = 0.f;
+#pragma unroll
+                for (int j = 0; j < NX; j++) a = __builtin_fmaf(row[j], w[P(j)], a);
+                out[i] = a;
+            }
+        };
+        auto row_dot_vec = [&](const float* row, const float* gv) {               // row . g (through the wavefront's vector slot)
+            lds_handoff();
+            if (cq == 0) tv[r] = rowok ? gv[r] : 0.f;
+            lds_handoff();
+            float a = 0.f;
+#pragma unroll
+            for (int j = 0; j < NX; j++) a = __builtin_fmaf(row[j], tv[j], a);
+            return a;
+        };
+
+        for (int i = threadIdx.x; i < N * NX; i += blockDim.x) g[i] = gam[NX + i];
+        __syncthreads();
+
+        // ---- reduction ----
+        for (int s = 1; s < N; s <<= 1) {
+            if (s == s_top) {   // the active rows (every s-th) move to LDS
+                const int na = N / s;
+                for (int e = threadIdx.x; e < na * BLK; e += blockDim.x) {
+                    const int u = e / BLK, o = e - u * BLK;
+                    const int i = s * (u + 1) - 1;
+                    lds.L[e] = S[(size_t)i * BROW + o];
+                    lds.D[e] = S[(size_t)i * BROW + BLK + o];
+                }
+                for (int e = threadIdx.x; e < na * NX; e += blockDim.x) {
+                    const int u = e / NX, o = e - u * NX;
+                    lds.g[e] = g[(size_t)(s * (u + 1) - 1) * NX + o];
+                }
+                __syncthreads();
+            }
+            const Tier& T = s >= s_top ? lds : glob;
+            const int cnt = N / (2 * s);
+            for (int t = wv; t < cnt; t += WAVES) {            // the eliminated rows' inverses
+                const int j = at(T, s - 1 + 2 * s * t);
+                float D[CW];
+                load_slice(T.D + (size_t)j * T.bs, D, 1.0f);
+                gj_quad_step<NX, CW, 0>(D, r, cq, cq * 4);
+                store_slice(T.Wd + (size_t)j * T.bs, D);
+            }
+            __syncthreads();
+            for (int t = wv; t < cnt; t += WAVES) {            // the kept rows take both neighbours in
+                const int ri = 2 * s - 1 + 2 * s * t;
+                const bool has_ll = ri - 2 * s >= 0, has_r = ri + s < N;     // wavefront-uniform
+                const int i = at(T, ri), jm = at(T, ri - s), jp = at(T, has_r ? ri + s : ri);
+                float* Li_p = T.L + (size_t)i * T.bs;
+                float* Di_p = T.D + (size_t)i * T.bs;
+#ifndef GATO_DOUBLE
+                {
+                    typedef float mf4 __attribute__((ext_vector_type(4)));
+                    constexpr int LM = 17;
+                    const int mn = lane & 15, mg = lane >> 4;   // MFMA coordinates: operand row / column, k group = output row group
+                    float* T0 = tiles[wv][0];
+                    float* T1 = tiles[wv][1];
+                    float* T2 = tiles[wv][2];
+                    float* T3 = tiles[wv][3];
+                    // a block in the MFMA's accumulator layout: v[q] = entry (4 mg + q, mn); zero outside NX x NX
+                    auto gload = [&](const float* blk, float* v) {
+#pragma unroll
+                        for (int q = 0; q < 4; q++) v[q] = (4 * mg + q < NX && mn < NX) ? blk[(size_t)(4 * mg + q) * NX + mn] : 0.f;
+                    };
+                    auto gstore = [&](float* blk, const float* v) {
+#pragma unroll
+                        for (int q = 0; q < 4; q++)
+                            if (4 * mg + q < NX && mn < NX) blk[(size_t)(4 * mg + q) * NX + mn] = v[q];
+                    };
+                    auto tput = [&](float* t, const float* v) {
+                        lds_handoff();   // the tile's previous readers are done
+#pragma unroll
+                        for (int q = 0; q < 4; q++) t[(4 * mg + q) * LM + mn] = v[q];
+                        lds_handoff();
+                    };
+                    // c += op(X) op(Y), X and Y 16 x 16 tiles: four issues over k; operand layout a = A[mn][4 kk + mg], b = B[4 kk + mg][mn]
+                    auto mm = [&](const float* X, bool xT, const float* Y, bool yT, mf4 c) {
+#pragma unroll
+                        for (int kk = 0; kk < 4; kk++) {
+                            const int kx = 4 * kk + mg;
+                            const float av = xT ? X[kx * LM + mn] : X[mn * LM + kx];
+                            const float bv = yT ? Y[mn * LM + kx] : Y[kx * LM + mn];
+                            c = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, c, 0, 0, 0);
+                        }
+                        return c;
+                    };
+                    // rows of a tile times a vector, in the (r, cq) layout: sum over the lane's own columns, then over the quad
+                    auto tile_dot = [&](const float* t, float gval) {
+                        lds_handoff();
+                        if (cq == 0) tv[r] = gval;
+                        lds_handoff();
+                        float part = 0.f;
+#pragma unroll
+                        for (int q = 0; q < CW; q++) part = __builtin_fmaf(t[r * LM + c0 + q], (c0 + q < NX) ? tv[c0 + q] : 0.f, part);
+                        return quad_sum(part);
+                    };
+                    // every operand is fetched before the algebra starts (6 x 4 registers in this layout): one memory latency per task
+                    float li[4], dm[4], di[4], ljm[4], ljp[4], dp[4];
+                    gload(Li_p, li);
+                    gload(T.Wd + (size_t)jm * T.bs, dm);
+                    gload(Di_p, di);
+                    gload(T.L + (size_t)jm * T.bs, ljm);               // (meaningless and unused when !has_ll)
+                    gload(T.L + (size_t)jp * T.bs, ljp);               // (jp == i when !has_r: unused)
+                    gload(T.Wd + (size_t)jp * T.bs, dp);
+                    float gi = rowok ? T.g[(size_t)i * NX + r] : 0.f;
+                    const float gm = rowok ? T.g[(size_t)jm * NX + r] : 0.f;
+                    const float gp = rowok ? T.g[(size_t)jp * NX + r] : 0.f;
+                    const mf4 zero = {0.f, 0.f, 0.f, 0.f};
+                    tput(T0, li);
+                    tput(T1, dm);
+                    const mf4 wr = mm(T0, false, T1, false, zero);     // Wr = L_i D_jm^-1
+                    float w4[4] = {wr.x, wr.y, wr.z, wr.w};
+                    tput(T2, w4);
+                    mf4 ad = mm(T2, false, T0, true, zero);            // Wr L_i^T
+                    gi -= tile_dot(T2, gm);
+                    tput(T1, ljm);                                     // (the reads of D_jm^-1 are done: LDS is in order per wavefront)
+                    const mf4 nl = mm(T2, false, T1, false, zero);     // Wr L_jm
+                    float newL[4] = {has_ll ? -nl.x : 0.f, has_ll ? -nl.y : 0.f, has_ll ? -nl.z : 0.f, has_ll ? -nl.w : 0.f};
+                    if (has_r) {
+                        tput(T0, ljp);
+                        tput(T1, dp);
+                        const mf4 wl = mm(T0, true, T1, false, zero);  // Wl = L_jp^T D_jp^-1
+                        float v4[4] = {wl.x, wl.y, wl.z, wl.w};
+                        tput(T3, v4);
+                        ad = mm(T3, false, T0, false, ad);             // + Wl L_jp
+                        gi -= tile_dot(T3, gp);
+                    }
+                    di[0] -= ad.x; di[1] -= ad.y; di[2] -= ad.z; di[3] -= ad.w;
+                    gstore(T.Wc + (size_t)jm * T.bs, li);              // C_jm: what couples jm to its right neighbour, as of now
+                    gstore(Li_p, newL);
+                    gstore(Di_p, di);
+                    if (rowok && cq == 0) T.g[(size_t)i * NX + r] = gi;
+                    continue;
+                }
+#endif
+                float Di[CW], Li[CW], tmp[CW], acc[CW], newL[CW], row[NX], wrow[NX];
+                load_slice(Di_p, Di, 1.0f);
+                load_slice(Li_p, Li, 0.f);
+                float gi = rowok ? T.g[(size_t)i * NX + r] : 0.f;
+                // left neighbour jm:  Wr = L_i D_jm^-1
+                tile_put(tA, Li);
+                tile_row(tA, row);                                           // row r of L_i
+                load_slice(T.Wd + (size_t)jm * T.bs, tmp, 0.f);
+                tile_put(tB, tmp);
+                row_x_tile(row, tB, acc);                                    // Wr(r, own columns)
+                tile_put(tB, acc);
+                tile_row(tB, wrow);                                          // Wr(r, :)
+                row_x_tileT(wrow, tA, acc);                                  // Wr L_i^T
+#pragma unroll
+                for (int q = 0; q < CW; q++) Di[q] -= acc[q];
+                gi -= row_dot_vec(wrow, T.g + (size_t)jm * NX);
+                if (has_ll) {                                                // L_i <- - Wr L_jm  (the first active row has no left neighbour: 0)
+                    load_slice(T.L + (size_t)jm * T.bs, tmp, 0.f);
+                    tile_put(tB, tmp);
+                    row_x_tile(wrow, tB, newL);
+#pragma unroll
+                    for (int q = 0; q < CW; q++) newL[q] = -newL[q];
+                } else {
+#pragma unroll
+                    for (int q = 0; q < CW; q++) newL[q] = 0.f;
+                }
+                if (has_r) {                                                 // right neighbour jp:  Wl = L_jp^T D_jp^-1
+                    load_slice(T.L + (size_t)jp * T.bs, tmp, 0.f);
+                    tile_put(tA, tmp);                                       // L_jp
+                    tile_col(tA, row);                                       // row r of L_jp^T
+                    load_slice(T.Wd + (size_t)jp * T.bs, tmp, 0.f);
+                    tile_put(tB, tmp);
+                    row_x_tile(row, tB, acc);                                // Wl(r, own columns)
+                    tile_put(tB, acc);
+                    tile_row(tB, wrow);
+                    row_x_tile(wrow, tA, acc);                               // Wl L_jp
+#pragma unroll
+                    for (int q = 0; q < CW; q++) Di[q] -= acc[q];
+                    gi -= row_dot_vec(wrow, T.g + (size_t)jp * NX);
+                }
+                store_slice(T.Wc + (size_t)jm * T.bs, Li);                   // C_jm: what couples jm to its right neighbour, as of now
+                store_slice(Li_p, newL);
+                store_slice(Di_p, Di);
+                if (rowok && cq == 0) T.g[(size_t)i * NX + r] = gi;
+            }
+            __syncthreads();
+        }
+        // ---- the last block row (always in the LDS tier), then back substitution ----
+        if (wv == 0) {
+            const int e = at(lds, N - 1);
+            float D[CW];
+            load_slice(lds.D + (size_t)e * BLK, D, 1.0f);
+            gj_quad_step<NX, CW, 0>(D, r, cq, cq * 4);
+            if (cq == 0) tv[r] = rowok ? lds.g[(size_t)e * NX + r] : 0.f;
+            lds_handoff();
+            float part = 0.f;
+#pragma unroll
+            for (int i = 0; i < CW; i++) part = __builtin_fmaf(D[i], (c0 + i < NX) ? tv[c0 + i] : 0.f, part);
+            const float x = quad_sum(part);
+            if (rowok && cq == 0) lds.g[(size_t)e * NX + r] = x;
+        }
+        __syncthreads();
+        for (int s = N >> 1; s >= 1; s >>= 1) {
+            if (s < s_top && 2 * s >= s_top) {   // leaving the LDS tier: its rows' solutions go where the global tier looks for x
+                const int na = N / s_top;
+                for (int e = threadIdx.x; e < na * NX; e += blockDim.x) {
+                    const int u = e / NX, o = e - u * NX;
+                    g[(size_t)(s_top * (u + 1) - 1) * NX + o] = lds.g[e];
+                }
+                __syncthreads();
+            }
+            const Tier& T = s >= s_top ? lds : glob;
+            const int cnt = N / (2 * s);
+            for (int t = wv; t < cnt; t += WAVES) {
+                const int rj = s - 1 + 2 * s * t;                            // rj + s <= N - 1 always
+                const bool has_l = rj - s >= 0;
+                const int j = at(T, rj), jm = at(T, has_l ? rj - s : rj), jp = at(T, rj + s);
+                float rhs = rowok ? T.g[(size_t)j * NX + r] : 0.f;
+                float tmp[CW];
+                if (has_l) {                                                 // - L_j x_jm
+                    load_slice(T.L + (size_t)j * T.bs, tmp, 0.f);
+                    lds_handoff();
+                    if (cq == 0) tv[r] = rowok ? T.g[(size_t)jm * NX + r] : 0.f;
+                    lds_handoff();
+                    float part = 0.f;
+#pragma unroll
+                    for (int i = 0; i < CW; i++) part = __builtin_fmaf(tmp[i], (c0 + i < NX) ? tv[c0 + i] : 0.f, part);
+                    rhs -= quad_sum(part);
+                }
+                {                                                            // - C_j^T x_jp: the quad splits the rows of C_j
+                    const float* C = T.Wc + (size_t)j * T.bs;
+                    if (cq == 0) tv[16 + r] = rowok ? T.g[(size_t)jp * NX + r] : 0.f;
+                    lds_handoff();
+                    float part = 0.f;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const int i = cq + 4 * q;
+                        if (i < NX && rowok) part = __builtin_fmaf(C[(size_t)i * NX + r], tv[16 + i], part);
+                    }
+                    rhs -= quad_sum(part);
+                }
+                load_slice(T.Wd + (size_t)j * T.bs, tmp, 0.f);               // D_j^-1
+                lds_handoff();
+                if (cq == 0) tv[r] = rhs;
+                lds_handoff();
+                float part = 0.f;
+#pragma unroll
+                for (int i = 0; i < CW; i++) part = __builtin_fmaf(tmp[i], (c0 + i < NX) ? tv[c0 + i] : 0.f, part);
+                const float x = quad_sum(part);
+                if (rowok && cq == 0) T.g[(size_t)j * NX + r] = x;
+            }
+            __syncthreads();
+        }
+        if (s_top == 1) {   // short horizons never left LDS: the whole solution is there
+            for (int e = threadIdx.x; e < N * NX; e += blockDim.x) g[e] = lds.g[e];
+        }
+    }
+    if (threadIdx.x == 0) {
+        const uint32_t it = skip ? 0u : 1u;   // statistics as in the sweep: one "iteration", never converged by the 0-iterations rule
+        bf.pcg_iters[b] = it;
+        bf.st_pcg_iters[(size_t)sqp_iter * B + b] = (int32_t)it;
+        if (skip) atomicAdd(&bf.num_solved_w[sqp_iter], 1u);
+    }
+}
+
 // =========================================================================================================================
 // dz recovery (computeDzBatchedKernel, schur_linsys.cuh:316-431), one lane per (b,k); q, r are overwritten by the KKT residuals
 // =========================================================================================================================

@@ -554,9 +554,41 @@ template<class M> static void launch_pcg(GatoSolver* s, hipStream_t st, int sqp_
         }
     }
 }
-// opt-in direct solve of S lambda = gamma: one wavefront per trajectory
+// opt-in direct solve of S lambda = gamma.  Two kernels: the sweep (one wavefront per trajectory, N dependent block eliminations) and block
+// cyclic reduction (one workgroup of up to 16 wavefronts per trajectory, log2(N) levels of independent eliminations, the kept rows'
+// products on the matrix cores).  Measured on MI355X, one-iteration solves (tools/exp/direct_time.py -> DESIGN.md 5d): the reduction wins
+// wherever its workgroups are resident at once (indy7 N = 128, B = 1: 78 vs 310 us for the linear solve, PCG 236) and from N = 64 on at
+// every batch size (N = 128, B = 1024: 365 vs 446 us); the sweep keeps short horizons at full batches (N = 32, B = 1024: 104 vs 119 us).
+// GATO_DIRECT_CR = 0 / 1 forces the choice.
+static bool direct_uses_cr(const GatoSolver* s)
+{
+    const char* e = getenv("GATO_DIRECT_CR");
+    if (e) return atoi(e) != 0;
+    if (s->N < 8) return false;
+    if (s->N >= 64) return true;
+    const long waves = (long)s->B * (s->N >= 32 ? 16 : (s->N >= 16 ? 8 : 4));
+    return waves <= (long)s->cus * 16;   // every workgroup resident at once, four wavefronts per SIMD
+}
+template<class M, int WAVES> static void launch_cr(GatoSolver* s, hipStream_t st, int sqp_iter)
+{
+    constexpr int NX = 2 * M::NQ;
+    const size_t lds = (size_t)(4 * 16 * NX * NX + 16 * NX) * sizeof(float);   // the LDS tier: [L | D | D^-1 | C][16][nx^2] + g [16][nx]
+    static bool granted = false;   // per instantiation (plant x wavefronts); the static tiles + this exceed the 64 KB a kernel gets unasked
+    bool& ok = granted;
+    if (!ok) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&btd_cr_kernel<M, WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        ok = true;
+    }
+    hipLaunchKernelGGL((btd_cr_kernel<M, WAVES>), dim3(s->B), dim3(64 * WAVES), lds, st, s->bf, s->N, s->B, sqp_iter);
+}
 template<class M> static void launch_direct(GatoSolver* s, hipStream_t st, int sqp_iter)
 {
+    if (direct_uses_cr(s)) {
+        if (s->N >= 32 && !kDouble) launch_cr<M, 16>(s, st, sqp_iter);   // (float64 build: 8 wavefronts, its LDS tier is twice the size)
+        else if (s->N >= 16) launch_cr<M, 8>(s, st, sqp_iter);
+        else launch_cr<M, 4>(s, st, sqp_iter);
+        return;
+    }
     hipLaunchKernelGGL((btd_direct_kernel<M>), dim3(s->B), dim3(64), 0, st, s->bf, s->N, s->B, sqp_iter);
 }
 template<class M> static void launch_dz(GatoSolver* s, hipStream_t st, float dt, int sqp_iter)

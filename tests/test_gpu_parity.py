@@ -753,23 +753,27 @@ def test_symmetric_half_storage_pcg_kernel(plant, N, B, monkeypatch):
     assert traj_err(rs["XU"], ro["XU"]).max() < 2e-3
 
 
-@pytest.mark.parametrize("plant,N,B", [("indy7", 32, 9), ("iiwa14", 64, 5), ("iiwa14", 128, 2), ("indy7", 8, 3)])
-def test_direct_block_tridiagonal_solver(plant, N, B):
-    """Opt-in mode (gato_set_linear_solver): a block LU sweep over S lambda = gamma instead of PCG.  From the same S and
-    gamma its lambda must (a) solve the system -- checked against a float64 dense solve of the DEVICE's own S, 2e-4 of |lambda| -- and
-    (b) agree with a PCG run at its floor to 1e-3 (PCG's own fp32 floor); whole solves in this mode descend like the PCG ones."""
+@pytest.mark.parametrize("cr", ["0", "1"], ids=["sweep", "cyclic-reduction"])
+@pytest.mark.parametrize("plant,N,B", [("indy7", 32, 9), ("iiwa14", 64, 5), ("iiwa14", 128, 2), ("indy7", 8, 3), ("indy7", 128, 1), ("iiwa14", 16, 3)])
+def test_direct_block_tridiagonal_solver(plant, N, B, cr, monkeypatch):
+    """Opt-in mode (gato_set_linear_solver): S lambda = gamma solved directly instead of by PCG -- by the block LU sweep (one
+    wavefront per trajectory) or by block cyclic reduction (log2 N levels of independent eliminations over a workgroup; the small-batch form).
+    From the same S and gamma its lambda must (a) solve the system -- checked against a float64 dense solve of the DEVICE's own S, 2e-4 of
+    |lambda| -- and (b) agree with a PCG run at its floor to 1e-3 (PCG's own fp32 floor); whole solves in this mode descend like the PCG ones."""
     from gato_amd._lib import NativeSolver
+    monkeypatch.setenv("GATO_DIRECT_CR", cr)
     p = dict(DEFAULT_SOLVER_PARAMS, max_sqp_iters=1)
     pr = fig8_problem(plant, N, B, f_ext_std=1.0)
     xu, xs, ref = pr["xu"], pr["x_s"], pr["ref"]
     d = NativeSolver(plant, N, B, dt=DT, **p)
     d.set_f_ext_batch(pr["f_ext"])
     nx = d.nx
-    for st in ("kkt", "schur", "direct"):
+    for st in ("kkt", "schur"):
         d.stage(st, xu, DT, xs, ref)
-    lam = d.read("lambda").reshape(B, N + 2, nx).astype(np.float64)
-    S = d.read("S").reshape(B, N, nx, 3 * nx).astype(np.float64)
+    S = d.read("S").reshape(B, N, nx, 3 * nx).astype(np.float64)      # before the solve: the cyclic reduction works in place
     gam = d.read("gamma").reshape(B, N + 2, nx).astype(np.float64)
+    d.stage("direct", xu, DT, xs, ref)
+    lam = d.read("lambda").reshape(B, N + 2, nx).astype(np.float64)
     assert np.all(d.read("pcg_iters") == 1)
     for b in range(B):
         Sd = np.zeros((N * nx, N * nx))
@@ -779,7 +783,7 @@ def test_direct_block_tridiagonal_solver(plant, N, B):
                     Sd[k * nx:(k + 1) * nx, kk * nx:(kk + 1) * nx] = S[b, k][:, j * nx:(j + 1) * nx]
         exact = np.linalg.solve(Sd, gam[b, 1:N + 1].reshape(-1))
         err = np.abs(lam[b, 1:N + 1].reshape(-1) - exact).max() / np.abs(exact).max()
-        _report("direct_vs_dense_f64", plant=plant, N=N, b=b, err=err, cond=float(np.linalg.cond(Sd)))
+        _report("direct_vs_dense_f64", plant=plant, N=N, b=b, err=err, cond=float(np.linalg.cond(Sd)), kernel="cyclic reduction" if cr == "1" else "sweep")
         assert err < 2e-4, (b, err)                                   # fp32 sweep on a system of condition 1e9 .. 1e10 (measured <= 9e-5)
         assert np.all(lam[b, 0] == 0) and np.all(lam[b, N + 1] == 0)  # the padding blocks stay zero
     # (b) against PCG at its floor, same device blocks

@@ -26,6 +26,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--knots", type=int, nargs="+", default=[32])
     ap.add_argument("--sim-time", type=float, default=0.6)
+    ap.add_argument("--linear-solver", default="pcg", choices=["pcg", "direct"], help="direct: the block-tridiagonal direct solve (the small-batch / long-horizon mode)")
+    ap.add_argument("--batches", type=int, nargs="+", default=None)
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "mpc_heatmap.json"))
     a = ap.parse_args()
     from gato_amd.bsqp.common import figure8
@@ -36,15 +38,18 @@ def main():
     rows = []
     for N in a.knots:
         for i, B in enumerate(BATCHES):
+            if a.batches and B not in a.batches:
+                continue
             np.random.seed(0)
             mpc = MPC_GATO(None, None, N=N, dt=0.01, batch_size=B, plant_type="indy7")
+            mpc.solver.solver.set_linear_solver(a.linear_solver)
             # B in {2} cannot build the force estimator (it needs > 3 hypotheses, force_estimator.py:8): like the reference's benchmark
             # (benchmark_fig8.py passes no disturbance) the batch then carries identical zero-force hypotheses
             _, st = mpc.run_mpc_fig8(x0, fig8, sim_dt=0.001, sim_time=a.sim_time, solve_time_override=0.002, verbose=False)
             t = np.asarray(st["solve_times"])              # device time of the SQP solve inside the session call (hipEvents)
             w = 1e3 * np.asarray(mpc.step_wall_s[1:])      # host wall time of the WHOLE step call: transfers in, plant, prepare, solve, selection, read-back
             pub = PUBLISHED.get(N, [None] * 10)
-            r = dict(knots=N, batch=B, steps=int(t.size), mean_ms=float(t.mean()), median_ms=float(np.median(t)), p95_ms=float(np.percentile(t, 95)),
+            r = dict(knots=N, batch=B, linear_solver=a.linear_solver, steps=int(t.size), mean_ms=float(t.mean()), median_ms=float(np.median(t)), p95_ms=float(np.percentile(t, 95)),
                      step_wall_mean_ms=float(w.mean()), step_wall_median_ms=float(np.median(w)),
                      mean_goal_dist=float(np.mean(st["goal_distances"])), published_ms=pub[i] if i < len(pub) else None)
             rows.append(r)
