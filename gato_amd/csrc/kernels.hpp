@@ -3328,7 +3328,7 @@ __global__ __launch_bounds__(256) void ee_pos_kernel(float* __restrict__ out, co
 //   mpc_prepare_kernel   every row := best trajectory with its first state := the measured one; x_s, the reference window and the
 //                        wrench hypotheses (world frame -> last joint frame, mpc_controller.py:311-338) broadcast / transformed per row
 //   the SQP solve        (solver.hip:solve_impl, unchanged)
-//   select_best_kernel   hypothesis selection (mpc_controller.py:294-309), then mpc_take_best_kernel copies the winner
+//   select_best_kernel   hypothesis selection (mpc_controller.py:294-309), then mpc_finish_kernel takes the winner and writes the record the host reads
 // =========================================================================================================================
 // rows := warm start (x0 repeated over the knots, zero controls: common.py:93-99), best := the same, state := x0
 template<class M>
@@ -3433,30 +3433,29 @@ __global__ void add_remote_solved_kernel(uint32_t* __restrict__ global, const ui
     if (blockIdx.x == 0 && threadIdx.x == 0) global[it] = local[it] + remote[it];
 }
 
-// best trajectory := row *best of the batch (the winner of select_best_kernel; row 0 without a selection)
-__global__ __launch_bounds__(256) void mpc_take_best_kernel(float* __restrict__ xu_best, const float* __restrict__ xu, const int32_t* __restrict__ best, int traj, int B)
-{
-    int w = best ? *best : 0;
-    w = (w < 0 || w >= B) ? 0 : w;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < traj; i += gridDim.x * blockDim.x) xu_best[i] = xu[(size_t)w * traj + i];
-}
-
-// end effector of the session's state + the packed record the host reads back: [x (nx) | ee (3) | best (int bits)]
+// the end of a session step in ONE launch: best trajectory := row *best of the batch (the winner of select_best_kernel; row 0 without a
+// selection; skipped when take == 0: an advance-only step), and the packed record the host reads back: [x (nx) | ee (3) | best]
 template<class M>
-__global__ __launch_bounds__(64) void mpc_report_kernel(float* __restrict__ rec, const float* __restrict__ x, const int32_t* __restrict__ best)
+__global__ __launch_bounds__(256) void mpc_finish_kernel(float* __restrict__ xu_best, const float* __restrict__ xu, const int32_t* __restrict__ best, int traj, int B,
+                                                         int take, float* __restrict__ rec, const float* __restrict__ x)
 {
     constexpr int NQ = M::NQ, NX = 2 * NQ;
-    if (threadIdx.x != 0) return;
-    float q[NQ], e[3];
+    int w = (take && best) ? *best : 0;
+    w = (w < 0 || w >= B) ? 0 : w;
+    if (take)
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < traj; i += gridDim.x * blockDim.x) xu_best[i] = xu[(size_t)w * traj + i];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        float q[NQ], e[3];
 #pragma unroll
-    for (int i = 0; i < NQ; i++) q[i] = x[i];
-    RBD<M> d;
-    d.set_q(q);
-    d.ee_pos(e);
+        for (int i = 0; i < NQ; i++) q[i] = x[i];
+        RBD<M> d;
+        d.set_q(q);
+        d.ee_pos(e);
 #pragma unroll
-    for (int i = 0; i < NX; i++) rec[i] = x[i];
-    rec[NX] = e[0]; rec[NX + 1] = e[1]; rec[NX + 2] = e[2];
-    rec[NX + 3] = (float)(best ? *best : 0);
+        for (int i = 0; i < NX; i++) rec[i] = x[i];
+        rec[NX] = e[0]; rec[NX + 1] = e[1]; rec[NX + 2] = e[2];
+        rec[NX + 3] = (float)w;
+    }
 }
 
 }  // namespace gato

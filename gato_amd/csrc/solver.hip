@@ -88,7 +88,8 @@ struct GatoSolver {
     size_t ee_cap;
     float* d_plant;                        // staging of gato_plant_rk4 (x | wrench | control sequence), grown on demand
     // MPC session (gato_mpc_*): state, previous state, best trajectory, reference window, world-frame hypotheses, plant wrench, record
-    float *d_mpc_x, *d_mpc_xlast, *d_mpc_best, *d_mpc_refw, *d_mpc_hyp, *d_mpc_fw, *d_mpc_rec;
+    float *d_mpc_x, *d_mpc_xlast, *d_mpc_best, *d_mpc_refw, *d_mpc_hyp, *d_mpc_fw, *d_mpc_rec, *d_mpc_err;
+    float *h_mpc_in = nullptr, *h_mpc_out = nullptr;   // pinned mirrors of [wrench | window | hypotheses] and [record | errors]: one copy each way per step
     hipEvent_t mpc_ev0, mpc_ev1;
     bool mpc_begun = false;
     // sharded batch (gato_comm_init): this solver holds rows [rank B, (rank + 1) B) of a batch of global_batch trajectories
@@ -207,8 +208,11 @@ static int create_impl(GatoSolver* s, int plant, int N, int B, const GatoParams*
     DA(s->d_merit_init0, B); DA(s->d_drho_init, B); DA(s->d_rho_init, B);
     DA(s->d_sim_x, nx); DA(s->d_sim_u, nu); DA(s->d_sim_out, (size_t)B * nx);
     DA(s->d_sel_xm, nx); DA(s->d_sel_err, B); DA(s->d_sel_best, 2);
-    DA(s->d_mpc_x, nx); DA(s->d_mpc_xlast, nx); DA(s->d_mpc_best, s->traj); DA(s->d_mpc_refw, 6 * (size_t)N); DA(s->d_mpc_hyp, 6 * (size_t)B);
-    DA(s->d_mpc_fw, 6); DA(s->d_mpc_rec, nx + 4);
+    DA(s->d_mpc_x, nx); DA(s->d_mpc_xlast, nx); DA(s->d_mpc_best, s->traj);
+    DA(s->d_mpc_fw, 8 + 6 * (size_t)N + 6 * (size_t)B);   // [wrench (6, padded to 8) | reference window | world-frame hypotheses], one H2D copy
+    s->d_mpc_refw = s->d_mpc_fw + 8; s->d_mpc_hyp = s->d_mpc_refw + 6 * (size_t)N;
+    DA(s->d_mpc_rec, 20 + (size_t)B);                         // [record (nx + 4, padded to 20) | selection errors], one D2H copy
+    s->d_mpc_err = s->d_mpc_rec + 20;
 #undef DA
     s->d_ee_q = s->d_ee_out = nullptr;
     s->ee_cap = 0;
@@ -274,6 +278,8 @@ extern "C" int gato_destroy(GatoSolver* s)
     if (s->d_ee_out) (void)hipFree(s->d_ee_out);
     if (s->d_plant) (void)hipFree(s->d_plant);
     if (s->graph_exec) (void)hipGraphExecDestroy(s->graph_exec);
+    if (s->h_mpc_in) (void)hipHostFree(s->h_mpc_in);
+    if (s->h_mpc_out) (void)hipHostFree(s->h_mpc_out);
     if (s->mpc_ev0) (void)hipEventDestroy(s->mpc_ev0);
     if (s->mpc_ev1) (void)hipEventDestroy(s->mpc_ev1);
     if (s->own_stream) (void)hipStreamDestroy(s->own_stream);
@@ -1270,6 +1276,10 @@ extern "C" int gato_mpc_begin(GatoSolver* s, const float* x0)
     int rc = sync_last(s);
     if (rc) return rc;
     if (!s->mpc_ev0) { HIPCHK(hipEventCreate(&s->mpc_ev0)); HIPCHK(hipEventCreate(&s->mpc_ev1)); }
+    if (!s->h_mpc_in) {
+        HIPCHK(hipHostMalloc((void**)&s->h_mpc_in, (8 + 6 * (size_t)s->N + 6 * (size_t)s->B) * sizeof(float), hipHostMallocDefault));
+        HIPCHK(hipHostMalloc((void**)&s->h_mpc_out, (20 + (size_t)s->B) * sizeof(float), hipHostMallocDefault));
+    }
     rc = s->plant == GATO_PLANT_INDY7 ? mpc_begin_impl<Indy7>(s, x0) : mpc_begin_impl<Iiwa14>(s, x0);
     if (rc == GATO_OK) s->mpc_begun = true;
     return rc;
@@ -1277,18 +1287,26 @@ extern "C" int gato_mpc_begin(GatoSolver* s, const float* x0)
 template<class M> static int mpc_step_impl(GatoSolver* s, GatoMpcStep* io)
 {
     hipStream_t st = s->own_stream;
-    const bool advance = (io->phases & GATO_MPC_ADVANCE) != 0, plan = (io->phases & GATO_MPC_PLAN) != 0;
-    if (advance && io->plant_steps > 0) {
-        if (!(io->steps_per_knot > 0.0)) return fail(GATO_ERR_INVALID, "steps_per_knot must be positive");
-        HIPCHK(hipMemcpyAsync(s->d_mpc_fw, io->plant_wrench, 6 * sizeof(float), hipMemcpyHostToDevice, st));
+    const bool advance = (io->phases & GATO_MPC_ADVANCE) != 0 && io->plant_steps > 0, plan = (io->phases & GATO_MPC_PLAN) != 0;
+    if (advance && !(io->steps_per_knot > 0.0)) return fail(GATO_ERR_INVALID, "steps_per_knot must be positive");
+    if (plan && !io->ref_window) return fail(GATO_ERR_INVALID, "ref_window is required for GATO_MPC_PLAN");
+    // ONE host-to-device copy from pinned memory: [wrench | reference window | hypotheses] (only as far as this step needs)
+    {
+        const size_t nw = 6 * (size_t)s->N, nh = 6 * (size_t)s->B;
+        for (int i = 0; i < 6; i++) s->h_mpc_in[i] = advance ? io->plant_wrench[i] : (float)0;
+        size_t n = 8;
+        if (plan) {
+            memcpy(s->h_mpc_in + 8, io->ref_window, nw * sizeof(float));
+            n += nw;
+            if (io->hyp_world) { memcpy(s->h_mpc_in + 8 + nw, io->hyp_world, nh * sizeof(float)); n += nh; }
+        }
+        if (advance || plan) HIPCHK(hipMemcpyAsync(s->d_mpc_fw, s->h_mpc_in, n * sizeof(float), hipMemcpyHostToDevice, st));
+    }
+    if (advance)
         hipLaunchKernelGGL((mpc_plant_kernel<M>), dim3(1), dim3(64), 0, st, s->d_mpc_x, s->d_mpc_xlast, (const float*)s->d_mpc_best, (const float*)s->d_mpc_fw,
                            (int)io->plant_steps, io->sim_dt, io->steps_per_knot, s->N);
-    }
     const bool selecting = plan && io->select && s->B > 1;
     if (plan) {
-        if (!io->ref_window) return fail(GATO_ERR_INVALID, "ref_window is required for GATO_MPC_PLAN");
-        HIPCHK(hipMemcpyAsync(s->d_mpc_refw, io->ref_window, (size_t)6 * s->N * sizeof(float), hipMemcpyHostToDevice, st));
-        if (io->hyp_world) HIPCHK(hipMemcpyAsync(s->d_mpc_hyp, io->hyp_world, (size_t)6 * s->B * sizeof(float), hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL((mpc_prepare_kernel<M>), dim3(s->B), dim3(256), 0, st, s->d_xu_own, s->d_xs_own, s->d_ref_own, s->bf.f_ext, (const float*)s->d_mpc_best,
                            (const float*)s->d_mpc_x, (const float*)s->d_mpc_refw, io->hyp_world ? (const float*)s->d_mpc_hyp : (const float*)nullptr, s->N, s->traj);
         // reset_rho ahead of every solve (mpc_controller.py:229)
@@ -1303,21 +1321,19 @@ template<class M> static int mpc_step_impl(GatoSolver* s, GatoMpcStep* io)
             // every hypothesis against the state just measured
             uint32_t* cnt = reinterpret_cast<uint32_t*>(s->d_sel_best + 1);
             HIPCHK(hipMemsetAsync(cnt, 0, sizeof(uint32_t), st));
-            hipLaunchKernelGGL((select_best_kernel<M>), dim3(cdiv(s->B, 256)), dim3(256), 0, st, s->d_sim_out, s->d_sel_err, s->d_sel_best, cnt,
+            hipLaunchKernelGGL((select_best_kernel<M>), dim3(cdiv(s->B, 256)), dim3(256), 0, st, s->d_sim_out, s->d_mpc_err, s->d_sel_best, cnt,
                                (const float*)s->d_mpc_xlast, (const float*)(s->d_mpc_best + s->nx), (const float*)s->d_mpc_x, (const float*)s->bf.f_ext, s->B,
                                io->select_dt);
-        } else {
-            HIPCHK(hipMemsetAsync(s->d_sel_best, 0, sizeof(int32_t), st));
         }
-        hipLaunchKernelGGL(mpc_take_best_kernel, dim3(cdiv(s->traj, 256)), dim3(256), 0, st, s->d_mpc_best, (const float*)s->d_xu_own, (const int32_t*)s->d_sel_best,
-                           s->traj, s->B);
     }
-    hipLaunchKernelGGL((mpc_report_kernel<M>), dim3(1), dim3(64), 0, st, s->d_mpc_rec, (const float*)s->d_mpc_x, plan ? (const int32_t*)s->d_sel_best : (const int32_t*)nullptr);
+    // best row (after a plan) + the record, one launch; ONE device-to-host copy into pinned memory
+    hipLaunchKernelGGL((mpc_finish_kernel<M>), dim3(plan ? cdiv(s->traj, 256) : 1), dim3(256), 0, st, s->d_mpc_best, (const float*)s->d_xu_own,
+                       selecting ? (const int32_t*)s->d_sel_best : (const int32_t*)nullptr, s->traj, s->B, plan ? 1 : 0, s->d_mpc_rec, (const float*)s->d_mpc_x);
     HIPCHK(hipGetLastError());
-    float rec[20];
-    HIPCHK(hipMemcpyAsync(rec, s->d_mpc_rec, (size_t)(s->nx + 4) * sizeof(float), hipMemcpyDeviceToHost, st));
-    if (selecting && io->errors) HIPCHK(hipMemcpyAsync(io->errors, s->d_sel_err, (size_t)s->B * sizeof(float), hipMemcpyDeviceToHost, st));
+    const bool want_err = selecting && io->errors;
+    HIPCHK(hipMemcpyAsync(s->h_mpc_out, s->d_mpc_rec, (20 + (want_err ? (size_t)s->B : 0)) * sizeof(float), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    const float* rec = s->h_mpc_out;
     for (int i = 0; i < s->nx; i++) io->x[i] = rec[i];
     for (int i = 0; i < 3; i++) io->ee[i] = rec[s->nx + i];
     io->best = plan ? (int32_t)rec[s->nx + 3] : 0;
@@ -1327,8 +1343,8 @@ template<class M> static int mpc_step_impl(GatoSolver* s, GatoMpcStep* io)
         HIPCHK(hipEventElapsedTime(&ms, s->mpc_ev0, s->mpc_ev1));
         io->solve_us = (double)ms * 1e3;
     }
-    if (!selecting && io->errors)
-        for (int b = 0; b < s->B; b++) io->errors[b] = 0;
+    if (io->errors)
+        for (int b = 0; b < s->B; b++) io->errors[b] = want_err ? rec[20 + b] : (float)0;
     return GATO_OK;
 }
 extern "C" int gato_mpc_step(GatoSolver* s, GatoMpcStep* io)

@@ -23,6 +23,7 @@ BUDGETS = {
     r"kkt_kernelINS_6Iiwa14E": (256, 0, 64),
     r"step_kernelINS_5Indy7ELi512E": (128, 0, 0),                        # 4 wavefronts per SIMD: every C2 workgroup resident
     r"schur1_kernelINS_6Iiwa14ELb0E": (128, 0, 0),
+    r"btd_cr_kernelINS_\w+ELi16E": (128, 0, 0),                          # cyclic reduction, 16 wavefronts per workgroup: 1024 threads need <= 128
 }
 
 
