@@ -11,11 +11,13 @@ declare -A CMD
 CMD[c2]="$ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline"
 CMD[c3]="$ROOT/bench.py --plant iiwa14 --knots 128 --batch 256 --steps 5 --warmup 2 --no-cpu-baseline"
 CMD[c5]="$ROOT/bench.py --workload hparam --plant iiwa14 --knots 64 --batch 512 --steps 5 --warmup 2 --no-cpu-baseline"
-for cfg in c2 c3 c5; do
+# direct mode at a long horizon and a small batch: the cyclic-reduction kernel (the one place MFMA runs)
+CMD[cr]="$ROOT/tools/gpu_time.py --plant indy7 -N 128 -B 8 --iters 1 --reps 20 --solver direct"
+for cfg in c2 c3 c5 cr; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_${cfg} -o k -- python3 ${CMD[$cfg]} > $OUT/prof_${TAG}_${cfg}.log 2>&1
 done
 SETS=("FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32" "GRBM_GUI_ACTIVE GRBM_COUNT")
-for cfg in c2 c3 c5; do
+for cfg in c2 c3 c5 cr; do
   i=0
   for set in "${SETS[@]}"; do
     rocprofv3 --pmc $set --output-format csv -d $OUT/pmc_${TAG}_${cfg}_$i -o p -- python3 ${CMD[$cfg]} > $OUT/pmc_${TAG}_${cfg}_$i.log 2>&1

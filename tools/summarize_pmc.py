@@ -25,6 +25,7 @@ from collections import defaultdict
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CLOCK_HZ = 2.4e9          # MI355X peak engine clock (MI355X_MICROARCH.md, chip-level parameters)
 SIMDS = 256 * 4
+CONFIGS = ("c2", "c3", "c5", "cr")   # cr: direct mode, indy7 N=128 B=8 (block cyclic reduction)
 SRC = ["gato_amd/csrc/kernels.hpp", "gato_amd/csrc/rbd.hpp", "gato_amd/csrc/solver.hip", "gato_amd/csrc/robot_models.hpp"]
 
 
@@ -60,7 +61,7 @@ def main(tag):
            "_note": "rocprofv3 --kernel-trace --stats (avg_us) and --pmc passes (separate runs); FETCH/WRITE in bytes per dispatch (KiB x 1024), "
                     "hbm_bytes = 2 x fetch + write (gfx950 read-side correction, upper estimate), hbm_bytes_lower = fetch + write; SQ counters "
                     "are sums over the chip per dispatch; valu_issue_frac = SQ_INSTS_VALU x 4 cycles / (avg duration x 2.4 GHz x 1024 SIMDs)"}
-    for cfg in ("c2", "c3", "c5"):
+    for cfg in CONFIGS:
         stats_f = os.path.join(ROOT, "gpurun_out", "prof_%s_%s" % (tag, cfg), "k_kernel_stats.csv")
         if not os.path.exists(stats_f):
             continue
@@ -97,7 +98,7 @@ def main(tag):
                 d["mfma_busy_cycles"] = d["SQ_VALU_MFMA_BUSY_CYCLES"]   # no MFMA anywhere in this path: must read 0
         out[cfg] = kern
     json.dump(out, open(os.path.join(ROOT, "profiles", "pmc_summary.json"), "w"), indent=1, sort_keys=True)
-    for cfg in ("c2", "c3", "c5"):
+    for cfg in CONFIGS:
         if cfg not in out:
             continue
         print(cfg)
