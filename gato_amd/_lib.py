@@ -20,7 +20,7 @@ SYMBOLS = [
     "gato_last_error", "gato_version", "gato_reset_async", "gato_copy_final_merit_device", "gato_set_cost_weights_batch",
     "gato_synchronize", "gato_sim_forward_device", "gato_select_best", "gato_select_best_device",
     "gato_plant_rk4", "gato_fk_placements", "gato_set_linear_solver", "gato_set_graph_mode",
-    "gato_mpc_begin", "gato_mpc_step", "gato_mpc_get_best",
+    "gato_mpc_begin", "gato_mpc_step", "gato_mpc_get_best", "gato_plant_payload_rk4", "gato_mpc_set_payload", "gato_mpc_get_payload",
     "gato_comm_unique_id", "gato_comm_init", "gato_comm_destroy", "gato_gather_results", "gato_debug_set_remote_solved", "gato_abi_real_size",
 ]
 
@@ -119,6 +119,9 @@ def load(f64=False):
     L.gato_copy_final_merit_device.argtypes = [vp, vp, vp]
     L.gato_synchronize.argtypes = [vp]
     L.gato_plant_rk4.argtypes = [vp, fp, fp, C.c_int, fp, ft]
+    L.gato_plant_payload_rk4.argtypes = [vp, fp, fp, fp, C.c_int, fp, ft]
+    L.gato_mpc_set_payload.argtypes = [vp, fp]
+    L.gato_mpc_get_payload.argtypes = [vp, fp]
     L.gato_fk_placements.argtypes = [C.c_int, fp, C.POINTER(C.c_double)]
     L.gato_select_best.argtypes = [vp, fp, fp, fp, ft, C.POINTER(C.c_int), fp]
     L.gato_select_best_device.argtypes = [vp, vp, vp, vp, ft, vp, vp, vp]
@@ -320,6 +323,22 @@ class NativeSolver:
         u = self._f(u_seq).reshape(-1, self.nu)
         self._chk(self.L.gato_plant_rk4(self.h, self._p(x), self._p(u), int(u.shape[0]), self._p(self._f(f_ext6, (6,))), float(sim_dt)))
         return x
+
+    def plant_payload_rk4(self, x, pend11, u_seq, f_ext6, sim_dt):
+        """plant_rk4 with the swinging payload pend11 = [quat xyzw | w | mass, length, damping, inertia]; returns (new state, new pend11)"""
+        x = np.array(x, dtype=self.dtype).reshape(self.nx)
+        pend = np.array(pend11, dtype=self.dtype).reshape(11)
+        u = self._f(u_seq).reshape(-1, self.nu)
+        self._chk(self.L.gato_plant_payload_rk4(self.h, self._p(x), self._p(pend), self._p(u), int(u.shape[0]), self._p(self._f(f_ext6, (6,))), float(sim_dt)))
+        return x, pend
+
+    def mpc_set_payload(self, pend11):
+        self._chk(self.L.gato_mpc_set_payload(self.h, None if pend11 is None else self._p(self._f(pend11, (11,)))))
+
+    def mpc_payload(self):
+        out = np.zeros(7, self.dtype)
+        self._chk(self.L.gato_mpc_get_payload(self.h, self._p(out)))
+        return out
 
     # ---- MPC session (gato_mpc_*): one call per MPC step, the loop's state stays on the device ----
     def mpc_begin(self, x0):

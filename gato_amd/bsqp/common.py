@@ -23,3 +23,19 @@ def initialize_warm_start(x_start, N, nx, nu):
     for i in range(N):
         XU[i * (nx + nu): i * (nx + nu) + nx] = x_start
     return XU
+
+
+def sample_axis_angle(mag_range=(0.0, 0.6), rng=None):
+    """Axis-angle vector of the payload's initial rotation: a uniformly random direction times a magnitude drawn uniformly from
+    mag_range in radians (python/bsqp/common.py:121-136).  `rng` (a numpy Generator, extension) makes the draw reproducible."""
+    rng = np.random.default_rng() if rng is None else rng
+    direction = rng.normal(size=3)
+    direction /= np.linalg.norm(direction) + 1e-12
+    return direction * rng.uniform(*mag_range)
+
+
+def sample_pendulum_params(length_range=(0.3, 0.7), damping_range=(0.1, 0.6), angle_range=(0.0, 0.6), mass=15.0, rng=None):
+    """A random `pendulum_config` for MPC_GATO sweeps (python/bsqp/common.py:139-158): fixed mass, length in metres, damping in N m s / rad."""
+    rng = np.random.default_rng() if rng is None else rng
+    return {"mass": mass, "length": float(rng.uniform(*length_range)), "damping": float(rng.uniform(*damping_range)),
+            "initial_angle": sample_axis_angle(angle_range, rng)}

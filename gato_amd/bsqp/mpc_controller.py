@@ -15,7 +15,11 @@ device: the clock that turns measured latencies into plant steps, the reference 
 Semantics kept from the reference (cited where they are implemented): the plant advances by the latency of the previous step, one control per
 1-kHz step taken from knot min(int(i / (dt / sim_dt)), N-1), remainders accumulate into an extra step (:199-218); every solve starts from the
 best row of the previous one with its first state replaced by the measurement (:222-242); hypotheses are scored by one integrator step from the
-previous state (:294-309).  The plant is the library's own rigid-body model (no pinocchio), so the pendulum payload is not available.
+previous state (:294-309).  The plant is the library's own rigid-body model (no pinocchio).  `pendulum_config` (:44-60, 340-360) hangs a
+swinging payload from the SIMULATED arm only: the session's plant integrates arm + spherical joint + bob (`gato_mpc_set_payload`; the joint is
+eliminated articulated-body fashion, kernels.hpp payload_dynamics) with the joint torque -damping x velocity formed once per plant step
+(:472-478).  One deliberate difference: `initial_angle` is taken as the axis-angle vector its sampler produces (common.py:121-136); the reference
+writes it into the vector part of the joint's quaternion with w = 0 (:412-418), which pinocchio's integrate then pulls towards a half turn.
 `solve_time_override` (extension) fixes the simulated latency of every step so that a run is reproducible.
 """
 import time
@@ -69,13 +73,15 @@ class _Log:
 class MPC_GATO:
     def __init__(self, model=None, model_path=None, N=32, dt=0.03125, batch_size=1, constant_f_ext=None, track_full_stats=False, plant_type="indy7",
                  pendulum_config=None, solver_params=None):
-        if pendulum_config is not None:
-            raise NotImplementedError("pendulum_config needs a pinocchio model with a spherical joint; the MI355X library simulates the arm itself")
         cfg = dict(DEFAULT_SOLVER_PARAMS)
         cfg.update(solver_params or {})
         self.solver = BSQP(model_path=model_path, batch_size=batch_size, N=N, dt=dt, plant_type=plant_type, **cfg)
-        self.solver_params, self.plant_type, self.has_pendulum = cfg, plant_type, False
-        self.nq = self.nv = self.nq_robot = self.nv_robot = self.solver.nq
+        self.solver_params, self.plant_type = cfg, plant_type
+        self.pendulum_config, self.has_pendulum = pendulum_config, pendulum_config is not None
+        self.pendulum_state = None      # [quat x y z w | angular velocity] of the payload after the last run
+        self.nq_robot = self.nv_robot = self.solver.nq
+        # dimensions of the simulated model as the reference reports them (a spherical joint adds 4 configuration and 3 velocity entries, :94-95)
+        self.nq, self.nv = self.nq_robot + (4 if self.has_pendulum else 0), self.nv_robot + (3 if self.has_pendulum else 0)
         self.nx, self.nu = self.solver.nx, self.solver.nu
         self.N, self.dt, self.batch_size, self.track_full_stats = N, dt, batch_size, track_full_stats
         self.step_wall_s = []
@@ -103,7 +109,7 @@ class MPC_GATO:
 
     def _placements(self, q):
         from .. import _gato_ext
-        return _gato_ext.fk_placements(self.plant_type, np.asarray(q[: self.nq], np.float32))
+        return _gato_ext.fk_placements(self.plant_type, np.asarray(q[: self.nq_robot], np.float32))
 
     def transform_force_to_gato_frame(self, q, f_world, placements=None):
         """Host form of what the session does per hypothesis on the device (kernels.hpp:force_to_gato_frame; mpc_controller.py:311-338): the
@@ -140,8 +146,24 @@ class MPC_GATO:
         """device state := x_start, warm start, duals cleared; one solve on the first window before the clock starts (mpc_controller.py:170-176)"""
         dev = self.solver.solver
         dev.mpc_begin(np.asarray(x_start, np.float32))
+        dev.mpc_set_payload(self._payload_at_rest())
         return dev.mpc_step(advance=False, plan=True, plant_steps=0, sim_dt=0.0, steps_per_knot=1.0, plant_wrench=None, ref_window=window,
                             hyp_world=self._hypotheses(), select=False, select_dt=0.0)
+
+    def _payload_at_rest(self):
+        """[quat x y z w | w = 0 | mass, length, damping, inertia] from pendulum_config (defaults of mpc_controller.py:342-343, 417, 474; the bob's
+        own inertia 0.001 of :354), None without one"""
+        if not self.has_pendulum:
+            return None
+        c = self.pendulum_config
+        aa = np.asarray(c.get("initial_angle", [0.3, 0.0, 0.0]), np.float64).reshape(3)
+        ang = float(np.linalg.norm(aa))
+        quat = np.array([0.0, 0.0, 0.0, 1.0]) if ang < 1e-12 else np.concatenate([np.sin(ang / 2) * aa / ang, [np.cos(ang / 2)]])
+        return np.concatenate([quat, np.zeros(3), [c.get("mass", 15.0), c.get("length", 0.3), c.get("damping", 0.4), 0.001]]).astype(np.float32)
+
+    def _end(self):
+        if self.has_pendulum:
+            self.pendulum_state = np.asarray(self.solver.solver.mpc_payload(), np.float64)
 
     def _step(self, advance, plan, nsteps, sim_dt, window, latency):
         """one call into the session.  The selection integrates over the latency rounded to whole plant steps (mpc_controller.py:239)."""
@@ -185,9 +207,10 @@ class MPC_GATO:
             x = np.asarray(out["x"], np.float64)
             ee = np.asarray(out["ee"], np.float64)
             log.add(timestamps=clock.now, solve_times=out["solve_us"] / 1000.0, goal_distances=float(np.linalg.norm(ee - window[1, :3])), ee_actual=ee,
-                    joint_positions=x[: self.nq], joint_velocities=x[self.nq:])
+                    joint_positions=x[: self.nq_robot], joint_velocities=x[self.nq_robot:])
             if self.track_full_stats:
                 log.add(sqp_iters=self._iteration_counts()[0])
+        self._end()
         stats = log.finish()
         if verbose and len(stats["goal_distances"]):
             print(f"  mean tracking error {np.mean(stats['goal_distances']) * 1e3:.1f} mm, mean solve {np.mean(stats['solve_times']):.3f} ms over {len(stats['timestamps'])} steps")
@@ -220,7 +243,7 @@ class MPC_GATO:
             at = self._step(True, False, nsteps, sim_dt, None, latency)
             x, ee = np.asarray(at["x"], np.float64), np.asarray(at["ee"], np.float64)
             dist = float(np.linalg.norm(ee - goals[cur]))
-            arrived = dist < goal_threshold and np.abs(x[self.nq:]).sum() < velocity_threshold
+            arrived = dist < goal_threshold and np.abs(x[self.nq_robot:]).sum() < velocity_threshold
             if arrived or clock.now - since >= goal_timeout:
                 outcome[cur] = "reached" if arrived else "timeout"
                 if arrived:
@@ -231,11 +254,12 @@ class MPC_GATO:
                 window, since = window_of(goals[cur]), clock.now
             out = self._step(False, True, 0, sim_dt, window, latency)
             latency = (at["wall_s"] + out["wall_s"]) if solve_time_override is None else float(solve_time_override)
-            log.add(timestamps=clock.now, solve_times=out["solve_us"] / 1000.0, goal_distances=dist, ee_actual=ee, joint_positions=x[: self.nq],
-                    joint_velocities=x[self.nq:], best_trajectory_id=out["best"])
+            log.add(timestamps=clock.now, solve_times=out["solve_us"] / 1000.0, goal_distances=dist, ee_actual=ee, joint_positions=x[: self.nq_robot],
+                    joint_velocities=x[self.nq_robot:], best_trajectory_id=out["best"])
             if self.track_full_stats:
                 sqp, pcg = self._iteration_counts()
                 log.add(sqp_iters=sqp, pcg_iters=pcg)
+        self._end()
         stats = log.finish()
         stats["goal_outcomes"], stats["goal_reached_times"] = outcome, reached_at
         stats["time_to_all_reached"] = float(max(reached_at)) if all(o == "reached" for o in outcome) else None

@@ -3279,13 +3279,195 @@ template<class M> GATO_DEV void plant_rk4_step(float* q, float* v, const float* 
     }
 }
 
+// ---- the swinging payload of the MPC plant ------------------------------------------------------------------------------------------
+// MPC_GATO(pendulum_config=...) (mpc_controller.py:44-60, 340-360): the SIMULATED arm -- never the solver's model -- carries a pendulum: a
+// spherical joint at the last joint frame (placement identity), a bob of `mass` at (0, 0, -length) of the joint frame with inertia
+// `inertia` x 1 about its own centre (0.001 there), joint torque -damping x (relative angular velocity) (:472-478).  State beside the arm's:
+// the joint rotation as a unit quaternion (x, y, z, w: pendulum -> last-link coordinates, pinocchio's JointModelSpherical) and the relative
+// angular velocity in pendulum coordinates.
+// The joint is eliminated the articulated-body way (Featherstone, RBDA ch. 7, leaf step), in pendulum coordinates with c = (0, 0, -l):
+//   I_p = [[D, m c~], [m c~^T, m 1]], D = diag(ic + m l^2, ic + m l^2, ic);  S = [1; 0]  =>  U = I_p S, S^T U = D,
+//   I_a = I_p - U D^-1 U^T = blkdiag(0, diag(mu, mu, m)), mu = m ic / (ic + m l^2)   (the bob resists only along the rod, and a little across),
+//   p_a = p_A + I_a c_J + U D^-1 (tau - S^T p_A),  p_A = v_p x* I_p v_p,  c_J = v_p x S w.
+// The arm then is the arm with I_a added to its last link (RBD::minv's payload argument) and p_a + I_a a_L as one more wrench on it, and
+// afterwards  w' = D^-1 (tau - S^T p_A - U^T (X_p a_L + c_J)).  tests/pendulum_ref.py holds the same system un-eliminated in float64.
+struct Payload {
+    float mass, length, damping, inertia;
+};
+GATO_DEV void cross3(const float* a, const float* b, float* o)
+{
+    o[0] = a[1] * b[2] - a[2] * b[1];
+    o[1] = a[2] * b[0] - a[0] * b[2];
+    o[2] = a[0] * b[1] - a[1] * b[0];
+}
+// E = R(quat)^T: last-link coordinates -> pendulum coordinates
+GATO_DEV void quat_to_E(const float* qt, float (*E)[3])
+{
+    const float x = qt[0], y = qt[1], z = qt[2], w = qt[3];
+    E[0][0] = 1.f - 2.f * (y * y + z * z); E[1][0] = 2.f * (x * y - z * w);       E[2][0] = 2.f * (x * z + y * w);
+    E[0][1] = 2.f * (x * y + z * w);       E[1][1] = 1.f - 2.f * (x * x + z * z); E[2][1] = 2.f * (y * z - x * w);
+    E[0][2] = 2.f * (x * z - y * w);       E[1][2] = 2.f * (y * z + x * w);       E[2][2] = 1.f - 2.f * (x * x + y * y);
+}
+// pin.integrate on the spherical joint: quat (x) exp(w h), renormalised
+GATO_DEV void quat_integrate(const float* qt, const float* w, float h, float* out)
+{
+    const float tx = w[0] * h, ty = w[1] * h, tz = w[2] * h;
+    const float t2 = tx * tx + ty * ty + tz * tz;
+    float sv, cw;   // exp(theta) = (sv theta, cw)
+    if (t2 < 1e-8f) {
+        sv = 0.5f - t2 / 48.f;
+        cw = 1.f - t2 / 8.f;
+    } else {
+        const float t = sqrtf(t2);
+        float sn, cs;
+        sincosf(0.5f * t, &sn, &cs);
+        sv = sn / t;
+        cw = cs;
+    }
+    const float bx = sv * tx, by = sv * ty, bz = sv * tz;
+    const float ax = qt[0], ay = qt[1], az = qt[2], aw = qt[3];
+    float o[4];
+    o[0] = aw * bx + cw * ax + (ay * bz - az * by);
+    o[1] = aw * by + cw * ay + (az * bx - ax * bz);
+    o[2] = aw * bz + cw * az + (ax * by - ay * bx);
+    o[3] = aw * cw - (ax * bx + ay * by + az * bz);
+    const float n = 1.f / sqrtf(o[0] * o[0] + o[1] * o[1] + o[2] * o[2] + o[3] * o[3]);
+#pragma unroll
+    for (int i = 0; i < 4; i++) out[i] = o[i] * n;
+}
+// accelerations of the arm (qdd) and of the pendulum (wd) at (q, quat), (qd, w), control u, wrench fe on the last link, joint torque taup
+template<class M>
+GATO_DEV void payload_dynamics(const float* q, const float* qd, const float* quat, const float* w, const float* u, const float* fe, const float* taup,
+                               const Payload& pp, float* qdd, float* wd)
+{
+    constexpr int NQ = M::NQ, L = NQ - 1;
+    RBD<M> d;
+    d.set_q(q);
+    float v[NQ][6], a[NQ][6], f[NQ][6];
+    d.template rnea_fwd<0>(qd, nullptr, v, a);
+    float E[3][3];
+    quat_to_E(quat, E);
+    const float m = pp.mass, hz = -pp.mass * pp.length;                       // h = m c = (0, 0, hz)
+    const float Dx = pp.inertia + pp.mass * pp.length * pp.length, Dz = pp.inertia;
+    const float lam[3] = {pp.mass * pp.inertia / Dx, pp.mass * pp.inertia / Dx, pp.mass};
+    auto rot = [&](const float* x, float* o) {                                 // o = E x
+#pragma unroll
+        for (int r = 0; r < 3; r++) o[r] = E[r][0] * x[0] + E[r][1] * x[1] + E[r][2] * x[2];
+    };
+    auto rotT = [&](const float* x, float* o) {                                // o = E^T x
+#pragma unroll
+        for (int r = 0; r < 3; r++) o[r] = E[0][r] * x[0] + E[1][r] * x[1] + E[2][r] * x[2];
+    };
+    auto Ip_top = [&](const float* aw, const float* al, float* o) {            // S^T I_p [aw; al] = D aw + h x al
+        o[0] = Dx * aw[0] - hz * al[1];
+        o[1] = Dx * aw[1] + hz * al[0];
+        o[2] = Dz * aw[2];
+    };
+    float vp[6], cj[6];
+    rot(v[L], vp);
+    rot(v[L] + 3, vp + 3);
+    cross3(vp, w, cj);            // (E w_L + w) x w = (E w_L) x w
+    cross3(vp + 3, w, cj + 3);
+#pragma unroll
+    for (int i = 0; i < 3; i++) vp[i] += w[i];
+    float Iv[6], pA[6];
+    Ip_top(vp, vp + 3, Iv);
+    Iv[3] = m * vp[3] + hz * vp[1];   // m v - h x w
+    Iv[4] = m * vp[4] - hz * vp[0];
+    Iv[5] = m * vp[5];
+    RBD<M>::fxv(vp, Iv, pA);
+    float uj[3], y[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) uj[i] = taup[i] - pA[i];
+    y[0] = uj[0] / Dx; y[1] = uj[1] / Dx; y[2] = uj[2] / Dz;
+    // p_a: moment = taup (the joint carries nothing else), force = p_A + Lambda c_J + m c~^T y,  c~^T y = (0, 0, l) x y
+    float pa[3], paL[6], lamL[3][3], fx[6];
+    pa[0] = pA[3] + lam[0] * cj[3] + hz * y[1];
+    pa[1] = pA[4] + lam[1] * cj[4] - hz * y[0];
+    pa[2] = pA[5] + lam[2] * cj[5];
+    rotT(taup, paL);
+    rotT(pa, paL + 3);
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) lamL[r][c] = E[0][r] * lam[0] * E[0][c] + E[1][r] * lam[1] * E[1][c] + E[2][r] * lam[2] * E[2][c];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        fx[r] = fe[r] - paL[r];
+        fx[3 + r] = fe[3 + r] - paL[3 + r] - (lamL[r][0] * a[L][3] + lamL[r][1] * a[L][4] + lamL[r][2] * a[L][5]);
+    }
+    d.template rnea_force<0>(v, a, f, fx);
+    d.template rnea_bwd<NQ - 1>(f);
+    {
+        typename RBD<M>::MinvT Mi;
+        d.minv(Mi, lamL);
+        RBD<M>::fd_finish(Mi, u, f, qdd);
+    }
+    d.template rnea_fwd<0>(qd, qdd, v, a);
+    float ap[6], t[3];
+    rot(a[L], ap);
+    rot(a[L] + 3, ap + 3);
+#pragma unroll
+    for (int i = 0; i < 6; i++) ap[i] += cj[i];
+    Ip_top(ap, ap + 3, t);
+    wd[0] = (uj[0] - t[0]) / Dx;
+    wd[1] = (uj[1] - t[1]) / Dx;
+    wd[2] = (uj[2] - t[2]) / Dz;
+}
+// one step of common.py:49-91 `rk4` on the arm + payload model: pin.integrate is q + v h on the revolute joints and quat (x) exp(w h) on the
+// spherical one; the damping torque is formed once per step from the step's initial velocity, as the loop that calls rk4 does (mpc_controller.py:472-478)
+template<class M> GATO_DEV void payload_rk4_step(float* q, float* v, float* pend, const float* u, const float* fe, const Payload& pp, float h)
+{
+    constexpr int NQ = M::NQ;
+    const float hh = 0.5f * h;
+    float* quat = pend;
+    float* w = pend + 4;
+    const float taup[3] = {-pp.damping * w[0], -pp.damping * w[1], -pp.damping * w[2]};
+    float k1v[NQ], k2v[NQ], k3v[NQ], k4v[NQ], k2q[NQ], k3q[NQ], k4q[NQ], qs[NQ];
+    float k1w[3], k2w[3], k3w[3], k4w[3], k2o[3], k3o[3], k4o[3], qts[4];
+    payload_dynamics<M>(q, v, quat, w, u, fe, taup, pp, k1v, k1w);
+#pragma unroll
+    for (int i = 0; i < NQ; i++) { qs[i] = q[i] + v[i] * hh; k2q[i] = v[i] + k1v[i] * hh; }
+    quat_integrate(quat, w, hh, qts);
+#pragma unroll
+    for (int i = 0; i < 3; i++) k2o[i] = w[i] + k1w[i] * hh;
+    payload_dynamics<M>(qs, k2q, qts, k2o, u, fe, taup, pp, k2v, k2w);
+#pragma unroll
+    for (int i = 0; i < NQ; i++) { qs[i] = q[i] + k2q[i] * hh; k3q[i] = v[i] + k2v[i] * hh; }
+    quat_integrate(quat, k2o, hh, qts);
+#pragma unroll
+    for (int i = 0; i < 3; i++) k3o[i] = w[i] + k2w[i] * hh;
+    payload_dynamics<M>(qs, k3q, qts, k3o, u, fe, taup, pp, k3v, k3w);
+#pragma unroll
+    for (int i = 0; i < NQ; i++) { qs[i] = q[i] + k3q[i] * h; k4q[i] = v[i] + k3v[i] * h; }
+    quat_integrate(quat, k3o, h, qts);
+#pragma unroll
+    for (int i = 0; i < 3; i++) k4o[i] = w[i] + k3w[i] * h;
+    payload_dynamics<M>(qs, k4q, qts, k4o, u, fe, taup, pp, k4v, k4w);
+#pragma unroll
+    for (int i = 0; i < NQ; i++) {
+        const float avg = (v[i] + 2.f * k2q[i] + 2.f * k3q[i] + k4q[i]) / 6.f;
+        const float vn = v[i] + (h / 6.f) * (k1v[i] + 2.f * k2v[i] + 2.f * k3v[i] + k4v[i]);
+        q[i] = q[i] + avg * h;
+        v[i] = vn;
+    }
+    float avo[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) avo[i] = (w[i] + 2.f * k2o[i] + 2.f * k3o[i] + k4o[i]) / 6.f;
+    quat_integrate(quat, avo, h, qts);
+#pragma unroll
+    for (int i = 0; i < 3; i++) w[i] = w[i] + (h / 6.f) * (k1w[i] + 2.f * k2w[i] + 2.f * k3w[i] + k4w[i]);
+#pragma unroll
+    for (int i = 0; i < 4; i++) quat[i] = qts[i];
+}
+
 // The plant of the closed MPC loop: `nsteps` RK4 steps of the arm's forward dynamics under a constant wrench on the last link, one
 // control vector per step -- what python/bsqp/common.py:49-91 (`rk4`: k1..k4 from the articulated-body forward dynamics, revolute
 // joints so pin.integrate is q + v h) does with pinocchio between two solves of MPC_GATO.run_mpc_fig8 (mpc_controller.py:199-218).
 // Here the dynamics are the library's own (rbd.hpp, the tables the solver optimises with): one lane per plant instance.
 template<class M>
 __global__ __launch_bounds__(64) void plant_rk4_kernel(float* __restrict__ x_io, const float* __restrict__ u_seq, const float* __restrict__ f_ext,
-                                                       int nsteps, float h, int nplants)
+                                                       int nsteps, float h, int nplants, float* __restrict__ pend = nullptr)
 {
     constexpr int NQ = M::NQ, NX = 2 * NQ;
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -3295,11 +3477,26 @@ __global__ __launch_bounds__(64) void plant_rk4_kernel(float* __restrict__ x_io,
     for (int i = 0; i < NQ; i++) { q[i] = x_io[(size_t)p * NX + i]; v[i] = x_io[(size_t)p * NX + NQ + i]; }
 #pragma unroll
     for (int i = 0; i < 6; i++) fe[i] = f_ext[6 * p + i];
-    for (int s = 0; s < nsteps; s++) {
-        float u[NQ];
+    if (pend) {   // pend[p]: [quat (4) | w (3) | mass, length, damping, inertia]: the arm carries a swinging payload
+        float ps[7];
 #pragma unroll
-        for (int i = 0; i < NQ; i++) u[i] = u_seq[((size_t)p * nsteps + s) * NQ + i];
-        plant_rk4_step<M>(q, v, u, fe, h);
+        for (int i = 0; i < 7; i++) ps[i] = pend[11 * p + i];
+        const Payload pp = {pend[11 * p + 7], pend[11 * p + 8], pend[11 * p + 9], pend[11 * p + 10]};
+        for (int s = 0; s < nsteps; s++) {
+            float u[NQ];
+#pragma unroll
+            for (int i = 0; i < NQ; i++) u[i] = u_seq[((size_t)p * nsteps + s) * NQ + i];
+            payload_rk4_step<M>(q, v, ps, u, fe, pp, h);
+        }
+#pragma unroll
+        for (int i = 0; i < 7; i++) pend[11 * p + i] = ps[i];
+    } else {
+        for (int s = 0; s < nsteps; s++) {
+            float u[NQ];
+#pragma unroll
+            for (int i = 0; i < NQ; i++) u[i] = u_seq[((size_t)p * nsteps + s) * NQ + i];
+            plant_rk4_step<M>(q, v, u, fe, h);
+        }
     }
 #pragma unroll
     for (int i = 0; i < NQ; i++) { x_io[(size_t)p * NX + i] = q[i]; x_io[(size_t)p * NX + NQ + i] = v[i]; }
@@ -3349,25 +3546,37 @@ __global__ __launch_bounds__(256) void mpc_warm_kernel(float* __restrict__ xu, f
 // min(int(i / steps_per_knot), N - 1) of the best trajectory (mpc_controller.py:199-218; the quotient in double like the Python it mirrors)
 template<class M>
 __global__ __launch_bounds__(64) void mpc_plant_kernel(float* __restrict__ x, float* __restrict__ x_last, const float* __restrict__ xu_best,
-                                                       const float* __restrict__ fe6, int nsteps, float h, double steps_per_knot, int N)
+                                                       const float* __restrict__ fe6, int nsteps, float h, double steps_per_knot, int N,
+                                                       float* __restrict__ pend)
 {
     constexpr int NQ = M::NQ, NX = 2 * NQ, KS = 3 * NQ;
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
-    float q[NQ], v[NQ], fe[6];
+    float q[NQ], v[NQ], fe[6], ps[7];
+    Payload pp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < NQ; i++) { q[i] = x[i]; v[i] = x[NQ + i]; x_last[i] = q[i]; x_last[NQ + i] = v[i]; }
 #pragma unroll
     for (int i = 0; i < 6; i++) fe[i] = fe6[i];
+    if (pend) {   // the session's payload: [quat | w | mass, length, damping, inertia] (gato_mpc_set_payload)
+#pragma unroll
+        for (int i = 0; i < 7; i++) ps[i] = pend[i];
+        pp = {pend[7], pend[8], pend[9], pend[10]};
+    }
     for (int s = 0; s < nsteps; s++) {
         int k = (int)((double)s / steps_per_knot);
         k = k < N - 1 ? k : N - 1;
         float u[NQ];
 #pragma unroll
         for (int i = 0; i < NQ; i++) u[i] = xu_best[(size_t)k * KS + NX + i];
-        plant_rk4_step<M>(q, v, u, fe, h);
+        if (pend) payload_rk4_step<M>(q, v, ps, u, fe, pp, h);
+        else plant_rk4_step<M>(q, v, u, fe, h);
     }
 #pragma unroll
     for (int i = 0; i < NQ; i++) { x[i] = q[i]; x[NQ + i] = v[i]; }
+    if (pend) {
+#pragma unroll
+        for (int i = 0; i < 7; i++) pend[i] = ps[i];
+    }
 }
 
 // MPC_GATO.transform_force_to_gato_frame (mpc_controller.py:311-338) on the library's own kinematics: the world-frame wrench

@@ -188,8 +188,38 @@ class PyBSQP {
         return out;
     }
 
+    // the same plant with a swinging payload pend11 = [quat xyzw | w | mass, length, damping, inertia]: (new state, new pend11)
+    py::tuple plant_payload_rk4(farray x, farray pend11, farray u_seq, farray f_ext6, float sim_dt)
+    {
+        need(x, nx_, "x");
+        need(pend11, 11, "pend11");
+        need(f_ext6, 6, "f_ext6");
+        if (u_seq.size() % nu_) throw py::value_error("u_seq: expected [nsteps][nu] floats");
+        const int nsteps = (int)(u_seq.size() / nu_);
+        py::array_t<float> out((py::ssize_t)nx_), pend((py::ssize_t)11);
+        std::memcpy(out.mutable_data(), x.data(), nx_ * sizeof(float));
+        std::memcpy(pend.mutable_data(), pend11.data(), 11 * sizeof(float));
+        {
+            py::gil_scoped_release nogil;
+            chk(gato_plant_payload_rk4(s_, out.mutable_data(), pend.mutable_data(), u_seq.data(), nsteps, f_ext6.data(), sim_dt));
+        }
+        return py::make_tuple(out, pend);
+    }
+
     // ---- MPC session (gato_mpc_*, include/gato_abi.h): one call per MPC step, the loop's state stays on the device
     void mpc_begin(farray x0) { chk(gato_mpc_begin(s_, need(x0, nx_, "x0"))); }
+    void mpc_set_payload(py::object pend11)
+    {
+        if (pend11.is_none()) { chk(gato_mpc_set_payload(s_, nullptr)); return; }
+        farray p = pend11.cast<farray>();
+        chk(gato_mpc_set_payload(s_, need(p, 11, "pend11")));
+    }
+    py::array_t<float> mpc_payload()
+    {
+        py::array_t<float> out((py::ssize_t)7);
+        chk(gato_mpc_get_payload(s_, out.mutable_data()));
+        return out;
+    }
     py::dict mpc_step(bool advance, bool plan, int plant_steps, float sim_dt, double steps_per_knot, py::object plant_wrench, py::object ref_window,
                       py::object hyp_world, bool select, float select_dt)
     {
@@ -322,6 +352,9 @@ PYBIND11_MODULE(GATO_EXT_NAME, m)
         .def("ee_pos", &PyBSQP::ee_pos)
         .def("select_best", &PyBSQP::select_best)
         .def("plant_rk4", &PyBSQP::plant_rk4)
+        .def("plant_payload_rk4", &PyBSQP::plant_payload_rk4)
+        .def("mpc_set_payload", &PyBSQP::mpc_set_payload)
+        .def("mpc_payload", &PyBSQP::mpc_payload)
         .def("mpc_begin", &PyBSQP::mpc_begin)
         .def("mpc_step", &PyBSQP::mpc_step, py::arg("advance"), py::arg("plan"), py::arg("plant_steps"), py::arg("sim_dt"), py::arg("steps_per_knot"),
              py::arg("plant_wrench"), py::arg("ref_window"), py::arg("hyp_world"), py::arg("select"), py::arg("select_dt"))

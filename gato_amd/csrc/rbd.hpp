@@ -338,13 +338,21 @@ struct RBD {
         }
         if constexpr (K + 1 < NQ) minv_fwd<K + 1>(F, U, Dinv, Mi);
     }
-    GATO_DEV void minv(MinvT& Mi) const
+    // payload != nullptr: a body hanging from the last link through a joint that has been eliminated articulated-body fashion adds its
+    // articulated inertia blkdiag(0, payload) (3x3, force per linear acceleration, last-link frame) to the last link's (payload_dynamics, kernels.hpp)
+    GATO_DEV void minv(MinvT& Mi, const float (*payload)[3] = nullptr) const
     {
         float IA[36], F[NQ][6], U[NQ][6], Dinv[NQ];
 #pragma unroll
         for (int c = 0; c < 6; c++)
 #pragma unroll
             for (int r = 0; r < 6; r++) IA[6 * c + r] = M::I[NQ - 1][r][c];
+        if (payload) {
+#pragma unroll
+            for (int c = 0; c < 3; c++)
+#pragma unroll
+                for (int r = 0; r < 3; r++) IA[6 * (3 + c) + 3 + r] += payload[r][c];
+        }
 #pragma unroll
         for (int j = 0; j < NQ; j++)
 #pragma unroll

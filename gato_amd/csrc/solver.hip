@@ -89,6 +89,8 @@ struct GatoSolver {
     float* d_plant;                        // staging of gato_plant_rk4 (x | wrench | control sequence), grown on demand
     // MPC session (gato_mpc_*): state, previous state, best trajectory, reference window, world-frame hypotheses, plant wrench, record
     float *d_mpc_x, *d_mpc_xlast, *d_mpc_best, *d_mpc_refw, *d_mpc_hyp, *d_mpc_fw, *d_mpc_rec, *d_mpc_err;
+    float* d_mpc_pend;                     // the plant's swinging payload [quat | w | mass, length, damping, inertia] (gato_mpc_set_payload)
+    bool mpc_payload = false;
     float *h_mpc_in = nullptr, *h_mpc_out = nullptr;   // pinned mirrors of [wrench | window | hypotheses] and [record | errors]: one copy each way per step
     hipEvent_t mpc_ev0, mpc_ev1;
     bool mpc_begun = false;
@@ -208,7 +210,7 @@ static int create_impl(GatoSolver* s, int plant, int N, int B, const GatoParams*
     DA(s->d_merit_init0, B); DA(s->d_drho_init, B); DA(s->d_rho_init, B);
     DA(s->d_sim_x, nx); DA(s->d_sim_u, nu); DA(s->d_sim_out, (size_t)B * nx);
     DA(s->d_sel_xm, nx); DA(s->d_sel_err, B); DA(s->d_sel_best, 2);
-    DA(s->d_mpc_x, nx); DA(s->d_mpc_xlast, nx); DA(s->d_mpc_best, s->traj);
+    DA(s->d_mpc_x, nx); DA(s->d_mpc_xlast, nx); DA(s->d_mpc_best, s->traj); DA(s->d_mpc_pend, 12);
     DA(s->d_mpc_fw, 8 + 6 * (size_t)N + 6 * (size_t)B);   // [wrench (6, padded to 8) | reference window | world-frame hypotheses], one H2D copy
     s->d_mpc_refw = s->d_mpc_fw + 8; s->d_mpc_hyp = s->d_mpc_refw + 6 * (size_t)N;
     DA(s->d_mpc_rec, 20 + (size_t)B);                         // [record (nx + 4, padded to 20) | selection errors], one D2H copy
@@ -1201,6 +1203,38 @@ extern "C" int gato_plant_rk4(GatoSolver* s, float* x, const float* u_seq, int n
     return GATO_OK;
 }
 
+// The same plant carrying a swinging payload (MPC_GATO's pendulum_config: mpc_controller.py:44-60, 340-360, 472-478; kernels.hpp
+// payload_dynamics): pend11 = [quat x y z w | w (3) | mass, length, damping, inertia], the first seven updated in place.
+extern "C" int gato_plant_payload_rk4(GatoSolver* s, float* x, float* pend11, const float* u_seq, int nsteps, const float* f_ext6, float sim_dt)
+{
+    if (!s || !x || !pend11 || !f_ext6 || nsteps < 0 || (nsteps > 0 && !u_seq)) return fail(GATO_ERR_INVALID, "bad argument");
+    if (!(pend11[7] > 0) || !(pend11[8] > 0) || !(pend11[10] > 0)) return fail(GATO_ERR_INVALID, "payload mass, length and inertia must be positive");
+    if (nsteps == 0) return GATO_OK;
+    GUARD(s);
+    const size_t need = (size_t)s->nx + 6 + 12 + (size_t)nsteps * s->nu;
+    if (need > s->plant_cap) {
+        if (s->d_plant) (void)hipFree(s->d_plant);
+        s->d_plant = nullptr;
+        s->plant_cap = 0;
+        HIPCHK(hipMalloc((void**)&s->d_plant, (need + 64 * s->nu) * sizeof(float)));
+        s->plant_cap = need + 64 * s->nu;
+    }
+    float *d_x = s->d_plant, *d_f = d_x + s->nx, *d_p = d_f + 6, *d_u = d_p + 12;
+    std::vector<float> h(need);
+    memcpy(h.data(), x, s->nx * sizeof(float));
+    memcpy(h.data() + s->nx, f_ext6, 6 * sizeof(float));
+    memcpy(h.data() + s->nx + 6, pend11, 11 * sizeof(float));
+    memcpy(h.data() + s->nx + 18, u_seq, (size_t)nsteps * s->nu * sizeof(float));
+    HIPCHK(hipMemcpy(d_x, h.data(), need * sizeof(float), hipMemcpyHostToDevice));
+    if (s->plant == GATO_PLANT_INDY7) hipLaunchKernelGGL((plant_rk4_kernel<Indy7>), dim3(1), dim3(64), 0, nullptr, d_x, d_u, d_f, nsteps, sim_dt, 1, d_p);
+    else hipLaunchKernelGGL((plant_rk4_kernel<Iiwa14>), dim3(1), dim3(64), 0, nullptr, d_x, d_u, d_f, nsteps, sim_dt, 1, d_p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(h.data(), d_x, ((size_t)s->nx + 6 + 7) * sizeof(float), hipMemcpyDeviceToHost));
+    memcpy(x, h.data(), s->nx * sizeof(float));
+    memcpy(pend11, h.data() + s->nx + 6, 7 * sizeof(float));
+    return GATO_OK;
+}
+
 // World placements of the joint frames (pinocchio's data.oMi[1..nq], which MPC_GATO.transform_force_to_gato_frame reads,
 // mpc_controller.py:311-338) from the library's own kinematic tables: oMi_k = oMi_{k-1} [R0_k Rz(q_k) | r_k], R0_k = E0_k^T.
 // Host code, float64, no device: out[k] = {R row-major (9), p (3)}.
@@ -1304,7 +1338,7 @@ template<class M> static int mpc_step_impl(GatoSolver* s, GatoMpcStep* io)
     }
     if (advance)
         hipLaunchKernelGGL((mpc_plant_kernel<M>), dim3(1), dim3(64), 0, st, s->d_mpc_x, s->d_mpc_xlast, (const float*)s->d_mpc_best, (const float*)s->d_mpc_fw,
-                           (int)io->plant_steps, io->sim_dt, io->steps_per_knot, s->N);
+                           (int)io->plant_steps, io->sim_dt, io->steps_per_knot, s->N, s->mpc_payload ? s->d_mpc_pend : (float*)nullptr);
     const bool selecting = plan && io->select && s->B > 1;
     if (plan) {
         hipLaunchKernelGGL((mpc_prepare_kernel<M>), dim3(s->B), dim3(256), 0, st, s->d_xu_own, s->d_xs_own, s->d_ref_own, s->bf.f_ext, (const float*)s->d_mpc_best,
@@ -1357,6 +1391,29 @@ extern "C" int gato_mpc_step(GatoSolver* s, GatoMpcStep* io)
     int rc = sync_last(s);
     if (rc) return rc;
     return s->plant == GATO_PLANT_INDY7 ? mpc_step_impl<Indy7>(s, io) : mpc_step_impl<Iiwa14>(s, io);
+}
+// the session's plant carries a payload from now on (pend11 as in gato_plant_payload_rk4), or none (NULL)
+extern "C" int gato_mpc_set_payload(GatoSolver* s, const float* pend11)
+{
+    if (!s) return fail(GATO_ERR_INVALID, "null argument");
+    GUARD(s);
+    int rc = sync_last(s);
+    if (rc) return rc;
+    if (!pend11) { s->mpc_payload = false; return GATO_OK; }
+    if (!(pend11[7] > 0) || !(pend11[8] > 0) || !(pend11[10] > 0)) return fail(GATO_ERR_INVALID, "payload mass, length and inertia must be positive");
+    HIPCHK(hipMemcpyAsync(s->d_mpc_pend, pend11, 11 * sizeof(float), hipMemcpyHostToDevice, s->own_stream));
+    HIPCHK(hipStreamSynchronize(s->own_stream));
+    s->mpc_payload = true;
+    return GATO_OK;
+}
+extern "C" int gato_mpc_get_payload(GatoSolver* s, float* pend7)
+{
+    if (!s || !pend7) return fail(GATO_ERR_INVALID, "null argument");
+    GUARD(s);
+    if (!s->mpc_payload) return fail(GATO_ERR_INVALID, "the session's plant carries no payload (gato_mpc_set_payload)");
+    HIPCHK(hipMemcpyAsync(pend7, s->d_mpc_pend, 7 * sizeof(float), hipMemcpyDeviceToHost, s->own_stream));
+    HIPCHK(hipStreamSynchronize(s->own_stream));
+    return GATO_OK;
 }
 extern "C" int gato_mpc_get_best(GatoSolver* s, float* xu_best)
 {

@@ -180,6 +180,16 @@ int gato_mpc_get_best(GatoSolver* s, gato_real* xu_best);
  * place) with control u_seq[step] ([nsteps][nu], host) under the constant spatial wrench f_ext6 = [angular; linear] acting on the
  * last link, expressed in that link's frame. */
 int gato_plant_rk4(GatoSolver* s, gato_real* x, const gato_real* u_seq, int nsteps, const gato_real* f_ext6, gato_real sim_dt);
+/* The plant carrying a swinging payload: MPC_GATO(pendulum_config=...) (python/bsqp/mpc_controller.py:44-60; _add_pendulum_to_model :340-360:
+ * a pin.JointModelSpherical at the last joint frame, a bob of `mass` at (0, 0, -length) with inertia `inertia` x 1 about its centre -- 0.001
+ * there; the loop drives the joint with -damping x its velocity, :472-478).  Only the SIMULATED arm carries it, the solver's model never does.
+ *   pend11 = [quat x y z w | relative angular velocity (3, pendulum frame) | mass, length, damping, inertia]
+ * (pinocchio's configuration / velocity layout of the spherical joint); the first seven are the state, updated in place.
+ * gato_plant_payload_rk4 is gato_plant_rk4 with the payload; gato_mpc_set_payload gives the payload to the session's plant (NULL takes it
+ * away), gato_mpc_get_payload reads its state. */
+int gato_plant_payload_rk4(GatoSolver* s, gato_real* x, gato_real* pend11, const gato_real* u_seq, int nsteps, const gato_real* f_ext6, gato_real sim_dt);
+int gato_mpc_set_payload(GatoSolver* s, const gato_real* pend11);
+int gato_mpc_get_payload(GatoSolver* s, gato_real* pend7);
 /* World placements of the nq joint frames (pinocchio's data.oMi[1..nq] in mpc_controller.py:311-338) from the library's own
  * kinematic tables: out[k] = {R row-major (9 doubles), p (3 doubles)}.  Host-only, no device needed. */
 int gato_fk_placements(int plant, const gato_real* q, double* out);
