@@ -54,9 +54,38 @@ def bench_block(tag):
     return "Source: `profiles/%s_bench*.json` (the JSON lines of `bench.py`).\n\n" % tag + "\n".join(rows) + "\n"
 
 
+def heatmap_block():
+    """the reference's MPC solve-time heat-map next to this library's (profiles/r03_mpc_heatmap_*.json, tools/mpc_heatmap.py)"""
+    cells, pub = {}, {}
+    for f in ("short_pcg", "long_pcg", "long_direct"):
+        for c in json.load(open(os.path.join(ROOT, "profiles", "r03_mpc_heatmap_%s.json" % f))):
+            cells[(c["knots"], c["linear_solver"], c["batch"])] = c
+            if c.get("published_ms") is not None:
+                pub[(c["knots"], c["batch"])] = c["published_ms"]
+    batches = sorted({k[2] for k in cells})
+    rows = ["| N \\\\ batch | " + " | ".join(str(b) for b in batches) + " |", "|" + "---|" * (len(batches) + 1)]
+    ahead = {"pcg": 0, "best": 0}
+    for N in sorted({k[0] for k in cells}):
+        for ls in ("pcg", "direct"):
+            if (N, ls, batches[0]) not in cells:
+                continue
+            rows.append("| %d: this library, %s (ms) | " % (N, "PCG" if ls == "pcg" else "**direct**") +
+                        " | ".join("%.3f" % cells[(N, ls, b)]["mean_ms"] if (N, ls, b) in cells else "–" for b in batches) + " |")
+        rows.append("| %d: reference, published (ms) | " % N + " | ".join("%.2f" % pub[(N, b)] if (N, b) in pub else "–" for b in batches) + " |")
+        for b in batches:
+            if (N, b) in pub:
+                ahead["pcg"] += cells[(N, "pcg", b)]["mean_ms"] < pub[(N, b)]
+                ahead["best"] += min(cells[(N, ls, b)]["mean_ms"] for ls in ("pcg", "direct") if (N, ls, b) in cells) < pub[(N, b)]
+    w = {(N, b): cells[(N, "pcg", b)]["step_wall_mean_ms"] for (N, ls, b) in cells if ls == "pcg"}
+    tail = ("\nBy the device time of the solve, %d of the %d published cells are faster here with PCG and %d with the better of PCG and the direct mode; "
+            "host wall time of the whole session step (`step_wall_mean_ms`): %.2f ms at N = 32, B = 1, %.2f ms at B = 256.\n"
+            % (ahead["pcg"], len(pub), ahead["best"], w[(32, 1)], w[(32, 256)]))
+    return "\n".join(rows) + "\n" + tail
+
+
 def main(tag):
     pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_summary.json")))
-    blocks = {"kernels": kernels_block(pmc), "bench": bench_block(tag)}
+    blocks = {"kernels": kernels_block(pmc), "bench": bench_block(tag), "heatmap": heatmap_block()}
     p = os.path.join(ROOT, "DESIGN.md")
     s = open(p).read()
     for name, body in blocks.items():
@@ -70,4 +99,4 @@ def main(tag):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else "r03a")
+    main(sys.argv[1] if len(sys.argv) > 1 else "r03b")
