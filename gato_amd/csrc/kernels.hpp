@@ -464,7 +464,7 @@ template<int n, bool THREE> GATO_DEV void gj_inverse(float* Mat)
 // D corrupted when f_ext != 0; caught by tests/test_gpu_parity.py).  As real functions every task body stays below 64 KB and is
 // reached through s_swappc.  not_tail_called: a call marked `tail` disables the no-callee-saved-registers optimisation and the task
 // would open with ~110 scratch stores of caller registers nobody needs.
-template<class M, int JA, int JB>
+template<class M, int JA, int JB, int JC = -1>
 __device__ __noinline__ __attribute__((not_tail_called)) void kkt_columns(float* __restrict__ D, float* __restrict__ c_out, const float* __restrict__ xu,
                                          const float* __restrict__ f_ext, float dt)
 {
@@ -478,7 +478,7 @@ __device__ __noinline__ __attribute__((not_tail_called)) void kkt_columns(float*
     for (int i = 0; i < 6; i++) fe[i] = f_ext[i];
     RBD<M> d;
     d.set_q(x);
-    d.template fd_grad_columns<JA, JB>(
+    d.template fd_grad_columns<JA, JB, JC>(
         x + NQ, x + NX, fe,
         [&](int J, const float* cq, const float* cd, const float* cm) {
             store_vec<NQ, NQ>(D + J * NQ, cq);
@@ -544,21 +544,31 @@ GATO_DEV void kkt_costs(const Buffers& bf, const Costs& cw, const float* x, cons
     if (!terminal) store_vec<NU, NU>(bf.Rdi + bk * NU, Rd);
 }
 
-// Tasks (grid.y = NT = (NQ+1)/2 + 1), one wavefront of 64 (b,k) lanes each, the same split for every batch size (results do not
-// depend on B):
-//   task g < NT-1: forward dynamics and the derivative columns g and NQ-1-g (a long and a short one: the cost of column J falls
-//                  with J); task 0 also stores the defect c_{k+1}
-//   task NT-1    : the cost blocks of knot k; its lane k = N-1 produces the terminal blocks from x_{N-2} and c_0 = x_0 - x_s.
+// Tasks: one wavefront of 64 (b,k) lanes each, the same split for every batch size (results do not depend on B).  Every column task pays
+// the common prefix (M^-1, two RNEA passes: ~3.7 k instructions) before its derivative columns (~1.4 k each, falling with J):
+//   NQ even (indy7):  task g < NQ/2: columns g and NQ-1-g (a long and a short one); task NQ/2: the cost blocks            -- 4 wavefronts
+//   NQ = 7 (iiwa14):  columns {0,5,6}, {1,3}, {2,4} (6.8 k / 7.1 k / 6.5 k instructions); task 3: the cost blocks            -- 4 wavefronts
+//     (was {0,6} {1,5} {2,4} {3} + costs = 5 wavefronts: at two wavefronts per SIMD a CU holds 8, so one 5-wavefront workgroup at a time and
+//     the 512 workgroups of C3 / C5 in two rounds; with 4, two fit and all are resident at once)
+//   task 0 also stores the defect c_{k+1}; the cost task's lane k = N-1 produces the terminal blocks from x_{N-2} and c_0 = x_0 - x_s.
 // __launch_bounds__(64, 2): two wavefronts per SIMD.  A lone wavefront issues one dependent VALU instruction per ~10 cycles; the
 // second one fills the gaps, which pays for the few spills the 256-register budget costs.
+template<class M> constexpr int kkt_tasks() { return (M::NQ == 7 ? 3 : (M::NQ + 1) / 2) + 1; }
 template<class M, int g> GATO_DEV void kkt_dispatch(int task, const Buffers& bf, const float* xu, const float* fe, float* Dout, size_t bk, float dt)
 {
     constexpr int NQ = M::NQ, NX = 2 * NQ;
-    if constexpr (g < (NQ + 1) / 2) {
-        if (task == g)
-            kkt_columns<M, g, NQ - 1 - g>(Dout, bf.c + (bk + 1) * NX, xu, fe, dt);
-        else
+    if constexpr (g < kkt_tasks<M>() - 1) {
+        if (task == g) {
+            if constexpr (NQ == 7) {
+                if constexpr (g == 0) kkt_columns<M, 0, 5, 6>(Dout, bf.c + (bk + 1) * NX, xu, fe, dt);
+                else if constexpr (g == 1) kkt_columns<M, 1, 3>(Dout, bf.c + (bk + 1) * NX, xu, fe, dt);
+                else kkt_columns<M, 2, 4>(Dout, bf.c + (bk + 1) * NX, xu, fe, dt);
+            } else {
+                kkt_columns<M, g, NQ - 1 - g>(Dout, bf.c + (bk + 1) * NX, xu, fe, dt);
+            }
+        } else {
             kkt_dispatch<M, g + 1>(task, bf, xu, fe, Dout, bk, dt);
+        }
     }
 }
 
@@ -567,10 +577,10 @@ template<class M, int g> GATO_DEV void kkt_dispatch(int task, const Buffers& bf,
 // lanes.  Written directly, every lane's 24-byte column pieces were separate 8-byte requests to different cache lines (54 per knot);
 // the request rate of those stores, not the arithmetic, bounded this kernel.
 template<class M>
-__global__ __launch_bounds__(64 * ((M::NQ + 1) / 2 + 1), 2) void kkt_kernel(Buffers bf, int N, int B, float dt, int sqp_iter, float thresh, int row0,
-                                                                             real4* __restrict__ zero4, uint32_t zero_n4)
+__global__ __launch_bounds__(64 * kkt_tasks<M>(), 2) void kkt_kernel(Buffers bf, int N, int B, float dt, int sqp_iter, float thresh, int row0,
+                                                                     real4* __restrict__ zero4, uint32_t zero_n4)
 {
-    constexpr int NQ = M::NQ, NX = 2 * NQ, NU = NQ, KS = NX + NU, NT = (NQ + 1) / 2 + 1, ND = 3 * NQ * NQ;
+    constexpr int NQ = M::NQ, NX = 2 * NQ, NU = NQ, KS = NX + NU, NT = kkt_tasks<M>(), ND = 3 * NQ * NQ;
     extern __shared__ __attribute__((aligned(16))) float ldsD[];
     if (zero_n4) {
         // the FIRST launch of a solve whose initial merit is formed by the first step launch (solver.hip:solve_impl): it clears what

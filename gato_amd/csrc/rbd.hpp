@@ -510,8 +510,8 @@ struct RBD {
         }
     }
     // columns JA and JB (JB == JA: one column) after one evaluation of the common prefix
-    template<int JA, int JB, class E, class F> GATO_DEV void fd_grad_columns(const float* qd, const float* u, const float* fext, E&& emit,
-                                                                              F&& after_qdd) const
+    template<int JA, int JB, int JC, class E, class F> GATO_DEV void fd_grad_columns(const float* qd, const float* u, const float* fext, E&& emit,
+                                                                                      F&& after_qdd) const
     {
         // phases in basic blocks of their own (see rnea_grad_col)
         MinvT Mi;
@@ -525,6 +525,7 @@ struct RBD {
         if (opaque_true()) rnea(qd, qdd, fext, v, a, f);
         grad_column<JA>(qd, v, a, f, Mi, emit);
         if constexpr (JB != JA) grad_column<JB>(qd, v, a, f, Mi, emit);
+        if constexpr (JC >= 0) grad_column<JC>(qd, v, a, f, Mi, emit);
     }
     // ---- forward kinematics: e = origin of the last joint frame, Jc[j] = d e / d q_j ------------------------------
     // p_{n-1} = r_{n-1}; p_i = r_i + R_i p_{i+1},  R_i = E_i^T      (chain of Xhom products, indy7_grid.cuh:1834-1901)

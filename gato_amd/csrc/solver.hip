@@ -313,7 +313,7 @@ template<class M> static void launch_kkt(GatoSolver* s, hipStream_t st, float dt
 {
     // The same task split for EVERY batch size: it changes the generated code (and with it the last bit of D), so choosing it by
     // batch size would make a trajectory's iterates depend on how many neighbours it has.
-    constexpr int NT = (M::NQ + 1) / 2 + 1;
+    constexpr int NT = kkt_tasks<M>();
     hipLaunchKernelGGL((kkt_kernel<M>), dim3(cdiv((long)s->B * s->N, 64)), dim3(64 * NT), (size_t)64 * 3 * M::NQ * M::NQ * sizeof(float), st, s->bf, s->N,
                        s->B, dt, sqp_iter, exit_threshold(s), row0, reinterpret_cast<real4*>(clear_slab ? s->zero_slab : nullptr),
                        clear_slab ? (uint32_t)(s->zero_words / 4) : 0u);
