@@ -1022,6 +1022,11 @@ __global__ __launch_bounds__(256) void schur1_kernel(Buffers bf, int N, int B, f
     __shared__ __attribute__((aligned(16))) float sQ[17 * NX + 2];
     __shared__ __attribute__((aligned(16))) float sR[16 * NU];
     __shared__ __attribute__((aligned(16))) float sC[17 * NX + 2];
+    // A_k and B_k of the workgroup's 16 knots, formed ONCE (every lane its own row) and read by the theta columns as 16-byte vectors: row x
+    // = [A_k[x][0..nx) | pad to 16 | B_k[x][0..nu) | pad to 8]; the group stride (+4) keeps the four groups of a wavefront on different banks
+    constexpr int ABR = 24, ABG = NX * ABR + 4;
+    static_assert(NX <= 16 && NU <= 8, "row layout of sAB");
+    __shared__ __attribute__((aligned(16))) float sAB[16 * ABG];
     if (bf.ctrl->done) return;
     if constexpr (ROW0) {
         if (blockIdx.y == 1) {  // the Q_0 rows: one lane per trajectory
@@ -1067,17 +1072,33 @@ __global__ __launch_bounds__(256) void schur1_kernel(Buffers bf, int N, int B, f
     const float* Dm = sD + grp * ND;
 
     float Ar[NX], Bri[NU], phi[NX], th[NX], gg;
+    float* ABg = sAB + grp * ABG;
     {
-        // own row of A_k (A_elem with a lane-dependent row) and of B_k R_k^-1
+        // own row of A_k (A_elem with a lane-dependent row) and of B_k, left in LDS for the group's theta columns; then B_k R_k^-1
+        float ab[ABR];
 #pragma unroll
         for (int c = 0; c < NX; c++) {
             const float d = Dm[c * NQ + rm];
             float v0 = (c == y) ? 1.0f : 0.f;
             if (c >= NQ) v0 = (upper && c - NQ == y) ? dt : v0;
             Ar[c] = v0 + coef * d;
+            ab[c] = Ar[c];
         }
 #pragma unroll
-        for (int c = 0; c < NU; c++) Bri[c] = (coef * Dm[2 * NQQ + c * NQ + rm]) * sRi[grp * NU + c];
+        for (int c = NX; c < 16; c++) ab[c] = 0.f;
+#pragma unroll
+        for (int c = 0; c < NU; c++) {
+            const float bu = coef * Dm[2 * NQQ + c * NQ + rm];   // B_elem(y, c)
+            ab[16 + c] = bu;
+            Bri[c] = bu * sRi[grp * NU + c];
+        }
+#pragma unroll
+        for (int c = 16 + NU; c < ABR; c++) ab[c] = 0.f;
+        if (act) {
+#pragma unroll
+            for (int c = 0; c < ABR; c += 4) *reinterpret_cast<real4*>(ABg + y * ABR + c) = make_real4(ab[c], ab[c + 1], ab[c + 2], ab[c + 3]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the rows are read by the other lanes of the group (same wavefront)
     }
     {
 #pragma unroll
@@ -1103,15 +1124,19 @@ __global__ __launch_bounds__(256) void schur1_kernel(Buffers bf, int N, int B, f
     {
 #pragma unroll
         for (int x = 0; x < NX; x++) {
-            // the record pointer is laundered per column: otherwise the optimiser keeps every D entry it has seen in a register for the
-            // columns that reuse it (a 147-register copy of D again, two wavefronts per SIMD); re-reading LDS costs less than that
-            const float* Dx = Dm;
-            asm volatile("" : "+v"(Dx));
+            // row x of A_k and B_k: six 16-byte LDS reads, the same for every lane of the group (a broadcast).  The values are the ones
+            // A_elem / B_elem form (same expression, same bits); the sums run in the same order.
+            float arow[ABR];
+#pragma unroll
+            for (int c = 0; c < ABR; c += 4) {
+                const real4 v = *reinterpret_cast<const real4*>(ABg + x * ABR + c);
+                arow[c] = v.x; arow[c + 1] = v.y; arow[c + 2] = v.z; arow[c + 3] = v.w;
+            }
             float sacc = 0.f, s2 = 0.f;
 #pragma unroll
-            for (int j = 0; j < NX; j++) sacc += phi[j] * A_elem<NQ>(Dx, x, j, dt, h2);
+            for (int j = 0; j < NX; j++) sacc += phi[j] * arow[j];
 #pragma unroll
-            for (int j = 0; j < NU; j++) s2 += Bri[j] * B_elem<NQ>(Dx, x, j, dt, h2);
+            for (int j = 0; j < NU; j++) s2 += Bri[j] * arow[16 + j];
             float t;
             if (x < NQ) t = tq[x];
             else t = (x - NQ == rm) ? td : 0.f;
