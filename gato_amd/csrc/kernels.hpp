@@ -3672,6 +3672,18 @@ __global__ __launch_bounds__(256) void mpc_prepare_kernel(float* __restrict__ xu
 }
 
 // sharded batch without a communicator (tests: gato_debug_set_remote_solved): the other shards' solved count of this iteration is given
+// reset_dual() and reset_rho() of a stream-ordered caller (gato_reset_async) in ONE launch: lambda := 0 (n reals), rho / drho := their
+// reset values.  Three runtime memset / copy kernels of ~5 us each sat between two solves of a loop that resets before every solve.
+__global__ __launch_bounds__(256) void reset_kernel(float* __restrict__ lambda, uint32_t n, float* __restrict__ rho, const float* __restrict__ rho_init,
+                                                    float* __restrict__ drho, const float* __restrict__ drho_init, int B)
+{
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x, T = gridDim.x * blockDim.x, n4 = n / 4;
+    for (uint32_t i = g; i < n4; i += T) reinterpret_cast<real4*>(lambda)[i] = make_real4(0.f, 0.f, 0.f, 0.f);
+    for (uint32_t i = 4 * n4 + g; i < n; i += T) lambda[i] = 0.f;
+    if (rho)
+        for (uint32_t i = g; i < (uint32_t)B; i += T) { rho[i] = rho_init[i]; drho[i] = drho_init[i]; }
+}
+
 __global__ void add_remote_solved_kernel(uint32_t* __restrict__ global, const uint32_t* __restrict__ local, const uint32_t* __restrict__ remote, int it)
 {
     if (blockIdx.x == 0 && threadIdx.x == 0) global[it] = local[it] + remote[it];

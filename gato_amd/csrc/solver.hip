@@ -1072,11 +1072,15 @@ extern "C" int gato_reset_async(GatoSolver* s, int dual, int rho, void* stream)
     if (!s) return fail(GATO_ERR_INVALID, "null solver");
     GUARD(s);
     hipStream_t st = (hipStream_t)stream;
-    if (dual) HIPCHK(hipMemsetAsync(s->bf.lambda, 0, (size_t)s->B * s->vecp * sizeof(float), st));
-    if (rho) {
-        HIPCHK(hipMemcpyAsync(s->bf.rho, s->d_rho_init, s->B * sizeof(float), hipMemcpyDeviceToDevice, st));
-        HIPCHK(hipMemcpyAsync(s->bf.drho, s->d_drho_init, s->B * sizeof(float), hipMemcpyDeviceToDevice, st));
-    }
+    if (!dual && !rho) return GATO_OK;
+    // one launch for both
+    const uint32_t n = dual ? (uint32_t)((size_t)s->B * s->vecp) : 0u;
+    size_t blocks = ((size_t)n / 4 + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > (size_t)s->cus * 8) blocks = (size_t)s->cus * 8;
+    hipLaunchKernelGGL(reset_kernel, dim3((unsigned)blocks), dim3(256), 0, st, s->bf.lambda, n, rho ? s->bf.rho : (float*)nullptr,
+                       (const float*)s->d_rho_init, s->bf.drho, (const float*)s->d_drho_init, s->B);
+    HIPCHK(hipGetLastError());
     return GATO_OK;
 }
 extern "C" int gato_copy_final_merit_device(GatoSolver* s, float* d_out, void* stream)

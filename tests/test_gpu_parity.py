@@ -862,3 +862,36 @@ def test_corner_sizes(plant, N, B):
         small.set_f_ext_batch(pb["f_ext"][:3])
         o3 = small.solve(pb["xu"][:3], DT, pb["x_s"][:3], pb["ref"][:3])
         np.testing.assert_array_equal(o3["XU"], out["XU"][:3])
+
+
+@pytest.mark.parametrize("plant,N,B", [("indy7", 8, 3), ("iiwa14", 4, 1), ("indy7", 32, 64)])
+def test_reset_async_is_reset_dual_plus_reset_rho(plant, N, B):
+    """gato_reset_async: reset_dual() and reset_rho() of a stream-ordered caller as ONE launch (kernels.hpp:reset_kernel) -- after a solve
+    that left duals and adapted penalties behind, each flag alone and both together do what the two blocking calls do."""
+    from gato_amd._lib import NativeSolver
+    pr = fig8_problem(plant, N, B, f_ext_std=1.0)
+    s = NativeSolver(plant, N, B, dt=DT, **dict(DEFAULT_SOLVER_PARAMS, max_sqp_iters=3))
+    rho0 = np.linspace(0.02, 0.3, B).astype(np.float32)
+    s.set_rho_penalty_batch(rho0, True)
+
+    def dirty():
+        s.solve(pr["xu"], DT, pr["x_s"], pr["ref"])
+        lam, rho = s.read("lambda"), s.read("rho")
+        assert np.abs(lam).max() > 0 and not np.array_equal(rho, rho0)
+        return lam, rho
+    lam, rho = dirty()
+    s.reset_async(True, False)
+    s.synchronize()
+    assert not s.read("lambda").any() and np.array_equal(s.read("rho"), rho)
+    lam, rho = dirty()
+    s.reset_async(False, True)
+    s.synchronize()
+    assert np.array_equal(s.read("lambda"), lam) and np.array_equal(s.read("rho"), rho0)
+    dirty()
+    s.reset_async(True, True)
+    s.synchronize()
+    a = {k: s.read(k) for k in ("lambda", "rho", "drho")}
+    dirty()
+    s.reset_dual(); s.reset_rho()
+    for k, v in a.items():
+        np.testing.assert_array_equal(s.read(k), v, err_msg=k)
