@@ -152,8 +152,8 @@ def cpu_baseline(plant, N, params, dt, sample_b, make_problem):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--plant", default="indy7")
     ap.add_argument("--knots", type=int, default=32)
     ap.add_argument("--batch", type=int, default=1024, help="trajectories per GPU")
