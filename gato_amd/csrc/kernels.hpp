@@ -2167,6 +2167,9 @@ __global__ __launch_bounds__(MAXT, 2) void pcgs_kernel(Buffers bf, int N, int B,
     if (!skip) {
         const float eps = bf.pcg_tol[b];
         const bool mainrole = t >= (T >> 1);
+        // a SIMD hosts one left-role and one main-role wavefront and the left one carries twice the multiply-adds of every product: served first,
+        // it is not held to every second issue slot while the main one still runs (launch 403.5 -> 397 us at C3; priorities 2 and 3 alike)
+        if (!mainrole) __builtin_amdgcn_s_setprio(2);
         const int u = mainrole ? t - (T >> 1) : t;
         const int k = u >> 1, h = u & 1;
         const int r0 = k * NX + h * HR;
