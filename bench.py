@@ -143,7 +143,7 @@ def cpu_baseline(plant, N, params, dt, sample_b, make_problem):
     o1 = solvers[0].solve(pr["xu"][:per], dt, pr["x_s"][:per], pr["ref"][:per])
     t1 = time.perf_counter() - t0
     single = per * o1["iters_done"] / t1
-    return {"value": rate, "unit": "traj-SQP-iter/s", "cores": cores, "kind": "port",
+    return {"value": rate, "unit": "trajectory-SQP-iterations/s", "cores": cores, "kind": "port",
             "sample": "first %d trajectories of the same workload, %d SQP iterations each, %d single-threaded oracle solvers side by side "
                       "(best of 3 passes, %.2f s); one thread alone: %.0f traj-SQP-iter/s" % (sample_b, iters[0], cores, t, single),
             "single_core_value": single}
