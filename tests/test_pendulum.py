@@ -147,3 +147,25 @@ def test_mpc_goals_with_a_swinging_payload():
     bare = MPC_GATO(N=8, dt=0.03125, batch_size=1, plant_type="indy7", solver_params={"max_sqp_iters": 2})
     _, st0 = bare.run_mpc_goals(x0, [goal], goal_timeout=0.3, solve_time_override=0.004, verbose=False)
     assert np.abs(st0["joint_positions"][-1] - st["joint_positions"][-1]).max() > 1e-4
+
+
+@pytest.mark.gpu
+def test_compiled_binding_and_fig8_loop_carry_the_payload():
+    """the pybind11 class's plant_payload_rk4 is the ctypes path's, bit for bit; the figure-8 loop runs with a payload as the goal loop does"""
+    from gato_amd._lib import NativeSolver
+    from gato_amd.bsqp.bsqpN8_indy7 import BSQP_1_float
+    from gato_amd.bsqp.common import figure8
+    from gato_amd.bsqp.config import INDY7_START_CONFIGS
+    from gato_amd.bsqp.mpc_controller import MPC_GATO
+    s = _state("indy7", 4)
+    x0 = np.concatenate([s["q"], s["qd"]]).astype(np.float32)
+    useq = np.tile(s["u"], (10, 1)).astype(np.float32)
+    p11 = _pend11(s, 0.4).astype(np.float32)
+    a_x, a_p = NativeSolver("indy7", 8, 1, dt=0.01).plant_payload_rk4(x0, p11, useq, s["fe"], 1e-3)
+    b_x, b_p = BSQP_1_float().plant_payload_rk4(x0, p11, useq, np.asarray(s["fe"], np.float32), 1e-3)
+    np.testing.assert_array_equal(np.asarray(b_x), a_x)
+    np.testing.assert_array_equal(np.asarray(b_p), a_p)
+    mpc = MPC_GATO(N=8, dt=0.03125, batch_size=1, plant_type="indy7", pendulum_config={"mass": 1.0, "length": 0.2}, solver_params={"max_sqp_iters": 2})
+    x_start = np.concatenate([INDY7_START_CONFIGS["ready"], np.zeros(6)])
+    _, st = mpc.run_mpc_fig8(x_start, figure8(0.03125), sim_time=0.2, solve_time_override=0.004, verbose=False)
+    assert len(st["timestamps"]) > 20 and np.isfinite(st["joint_positions"]).all() and abs(np.linalg.norm(mpc.pendulum_state[:4]) - 1) < 1e-5
