@@ -210,7 +210,7 @@ def main():
         # whole job falls back to torch.distributed for the results (and to per-shard counting, exact here: fig-8 / sweep rows do not converge)
         ok_t = torch.ones(1, device=dev)
         try:
-            connect(solver)
+            connect(solver)   # agrees on RCCL's availability across the ranks BEFORE any rank enters ncclCommInitRank: fails on all ranks or none
             probe = torch.full((4,), float(rank + 1), device=dev)
             got = torch.zeros(4 * world, device=dev)
             solver.gather_results(probe.data_ptr(), got.data_ptr(), 4, torch.cuda.current_stream().cuda_stream)
@@ -222,16 +222,18 @@ def main():
             print("rank %d: native communicator unavailable (%s)" % (rank, e), file=sys.stderr)
             ok_t.zero_()
         dist.all_reduce(ok_t, op=dist.ReduceOp.MIN)
-        native = bool(ok_t.item() > 0) and not a.torch_gather
-        if not bool(ok_t.item() > 0):
+        coupled = bool(ok_t.item() > 0)
+        native = coupled and not a.torch_gather
+        if coupled:
+            check_sharded_params(params["solve_ratio"], world, coupled=True)
+        else:
+            # explicit fallback: no rank has a usable communicator.  The shards count their own rows against the WHOLE batch's threshold (the
+            # other shards' counts taken as zero): exact exactly as long as no trajectory converges -- verified after the run (`ok` below)
             try:
                 solver.comm_destroy()
             except Exception:   # noqa: BLE001
                 pass
-        coupled = bool(ok_t.item() > 0)
-        if not coupled:
-            solver.debug_set_remote_solved(np.zeros(1, np.uint32), world * B)   # shards count alone: exact while nothing converges (checked below)
-        check_sharded_params(params["solve_ratio"], world, coupled=True)
+            solver.debug_set_remote_solved(np.zeros(1, np.uint32), world * B)
         collective = "ncclAllGather on the library's communicator" if native else "torch.distributed.all_gather_into_tensor"
     xu0 = torch.from_numpy(pr["xu"]).to(dev)
     x_s = torch.from_numpy(pr["x_s"]).to(dev)
@@ -306,7 +308,11 @@ def main():
         sync()
         ng = torch.tensor([e0.elapsed_time(e1) / max(2, a.steps // 4)], dtype=torch.float64, device=dev)
         dist.all_reduce(ng, op=dist.ReduceOp.MAX)
-        multi = {"collective": collective, "solved_count": "ncclAllReduce per SQP iteration inside the solve" if coupled else "per shard (no communicator)",
+        sh = solver.shard_stats()
+        multi = {"collective": collective,
+                 "solved_count": ("deferred" if os.environ.get("GATO_SOLVED_COUNT", "") != "periter" else "per_iteration") if coupled else "per shard (no communicator)",
+                 "solved_count_detail": ("speculative solve + ONE ncclAllReduce of the per-iteration count vector per solve; %d of %d solves replayed exactly"
+                                         % (sh["replays"], sh["deferred_solves"])) if coupled else "shards count alone: exact while nothing converges (checked)",
                  "per_rank_ms": {"min": float(own[:, 0].min()), "median": float(np.median(own[:, 0])), "max": float(own[:, 0].max())},
                  "gather_ms": {"mean_over_ranks": float(own[:, 1].mean()), "max_over_ranks": float(own[:, 1].max())},
                  "solve_ms_without_gather": float(ng.item())}
@@ -323,6 +329,27 @@ def main():
     ok = bool(np.all(np.isfinite(st["final_merit"])) and np.all(st["final_merit"] <= st["initial_merit"]) and np.any(st["final_merit"] < st["initial_merit"]))
     if world > 1 and not coupled:
         ok = ok and not bool(np.any(st["kkt_converged"]))   # shards that count alone are exact only while nothing converges
+    # a parity bit on the line itself (untimed tail; the oracle is the CHECKER here, never the thing measured): 16 rows spread over this rank's
+    # batch, solved by the CPU oracle from the same reset state -- the first SQP iteration's decisions (line-search step, PCG count +-1, initial
+    # merit) of the timed solves must be the oracle's.  Later iterations of a free-running fp32 solve are not comparable row by row.
+    parity = None
+    if rank == 0 and iters > 0 and st["ls_num_iters"] > 0:
+        try:
+            from oracle.oracle import OracleSolver
+            idx = np.unique(np.linspace(0, B - 1, 16).astype(int))
+            orc = OracleSolver(plant, N, len(idx), dt=dt, threads=min(usable_cores(), len(idx)), **dict(params, max_sqp_iters=1))
+            if "rho" in pr:
+                orc.set_rho_penalty_batch(pr["rho"][idx], True)
+            ro = orc.solve(pr["xu"][idx], dt, pr["x_s"][idx], pr["ref"][idx])
+            steps_eq = bool(np.array_equal(ro["ls_step_size"][0], st["ls_step_size"][0][idx]))
+            pcg_ok = bool(np.abs(ro["pcg_iters"][0].astype(int) - st["pcg_iters_all"][0][idx]).max() <= 1)
+            im = float(np.abs(ro["initial_merit"] - st["initial_merit"][idx]).max() / max(1e-30, np.abs(ro["initial_merit"]).max()))
+            parity = {"rows": int(len(idx)), "checker": "oracle/gato_oracle.c (fp32), first SQP iteration from the reset state",
+                      "first_iteration_steps_equal": steps_eq, "first_iteration_pcg_iters_within_1": pcg_ok, "initial_merit_rel_err": im}
+            ok = ok and steps_eq and pcg_ok and im < 1e-5
+        except Exception as e:   # noqa: BLE001
+            parity = {"error": "%s: %s" % (type(e).__name__, e)}
+            ok = False
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -385,6 +412,7 @@ def main():
                      "whole_iteration": {"algorithmic_bytes_per_traj_iter": iter_bytes,
                                          "hbm_frac": iter_bytes * value / world / 1e9 / HBM_PEAK_GBS}},
         "solution_ok": ok,
+        "parity_sample": parity,
     }
     if multi:
         line["multi_gpu"] = multi

@@ -22,6 +22,7 @@ SYMBOLS = [
     "gato_plant_rk4", "gato_fk_placements", "gato_set_linear_solver", "gato_set_graph_mode",
     "gato_mpc_begin", "gato_mpc_step", "gato_mpc_get_best", "gato_plant_payload_rk4", "gato_mpc_set_payload", "gato_mpc_get_payload",
     "gato_comm_unique_id", "gato_comm_init", "gato_comm_destroy", "gato_gather_results", "gato_debug_set_remote_solved", "gato_abi_real_size",
+    "gato_set_solved_count_mode", "gato_get_shard_stats",
 ]
 
 
@@ -37,7 +38,7 @@ def _mpc_struct(ft, name):
     return type(name, (C.Structure,), {"_fields_": [
         ("phases", C.c_int32), ("plant_steps", C.c_int32), ("sim_dt", ft), ("steps_per_knot", C.c_double), ("plant_wrench", ft * 6),
         ("ref_window", C.POINTER(ft)), ("hyp_world", C.POINTER(ft)), ("select", C.c_int32), ("select_dt", ft), ("x", ft * 16), ("ee", ft * 3),
-        ("best", C.c_int32), ("solve_us", C.c_double), ("errors", C.POINTER(ft))]})
+        ("best", C.c_int32), ("solve_us", C.c_double), ("errors", C.POINTER(ft)), ("plant_us", C.c_double)]})
 
 
 GatoParams = _params_struct(C.c_float, "GatoParams")
@@ -88,6 +89,8 @@ def load(f64=False):
     L.gato_comm_destroy.argtypes = [vp]
     L.gato_gather_results.argtypes = [vp, vp, vp, C.c_uint64, vp]
     L.gato_debug_set_remote_solved.argtypes = [vp, C.POINTER(C.c_uint32), C.c_int, C.c_int64]
+    L.gato_set_solved_count_mode.argtypes = [vp, C.c_int]
+    L.gato_get_shard_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.gato_default_params.argtypes = [C.POINTER(PT)]
     L.gato_default_params.restype = None
     L.gato_dims.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
@@ -362,7 +365,7 @@ class NativeSolver:
         io.errors = self._p(err)
         self._chk(self.L.gato_mpc_step(self.h, C.byref(io)))
         return {"x": np.array(io.x[: self.nx], self.dtype), "ee": np.array(io.ee[:3], self.dtype), "best": int(io.best), "solve_us": float(io.solve_us),
-                "errors": err}
+                "plant_us": float(io.plant_us), "errors": err}
 
     def mpc_best(self):
         out = np.zeros(self.traj, self.dtype)
@@ -393,6 +396,16 @@ class NativeSolver:
         """test hook: the other shards' solved counts per SQP iteration (no communicator); global_batch = 0 ends it"""
         a = np.ascontiguousarray(per_iter, dtype=np.uint32)
         self._chk(self.L.gato_debug_set_remote_solved(self.h, a.ctypes.data_as(C.POINTER(C.c_uint32)), int(a.size), int(global_batch)))
+
+    def set_solved_count_mode(self, mode):
+        """sharded solves: "deferred" (default: speculative run, ONE reduction of the count vector per solve, exact replay when the exit rule
+        fired) or "per_iteration" (one 4-byte all-reduce per SQP iteration)"""
+        self._chk(self.L.gato_set_solved_count_mode(self.h, {"per_iteration": 0, "deferred": 1}[mode]))
+
+    def shard_stats(self):
+        a, b = C.c_uint64(), C.c_uint64()
+        self._chk(self.L.gato_get_shard_stats(self.h, C.byref(a), C.byref(b)))
+        return {"deferred_solves": int(a.value), "replays": int(b.value)}
 
     def synchronize(self):
         self._chk(self.L.gato_synchronize(self.h))

@@ -11,7 +11,7 @@ def figure8(dt, A_x=0.4, A_z=0.4, offset=(0.0, 0.5, 0.6), period=6, cycles=5, th
     t = np.linspace(0, 2 * np.pi, int(period / dt))
     unrot = np.stack([offset[0] + A_x * np.sin(t), np.full_like(t, offset[1]), offset[2] + A_z * np.sin(2 * t) / 2 + A_z / 2])
     R = np.array([[np.cos(theta), -np.sin(theta), 0.0], [np.sin(theta), np.cos(theta), 0.0], [0.0, 0.0, 1.0]])
-    rot = np.einsum("ij,jt->it", R, unrot) if False else np.stack([R[i, 0] * unrot[0] + R[i, 1] * unrot[1] + R[i, 2] * unrot[2] for i in range(3)])
+    rot = np.stack([R[i, 0] * unrot[0] + R[i, 1] * unrot[1] + R[i, 2] * unrot[2] for i in range(3)])   # the float sequence of the reference's loop
     pts = np.zeros((t.size, 6))
     pts[:, :3] = rot.T
     return np.tile(pts.reshape(-1), int(cycles))

@@ -174,6 +174,10 @@ class MPC_GATO:
                            ref_window=window, hyp_world=hyp, select=plan and hyp is not None, select_dt=max(sim_dt, round(latency / sim_dt) * sim_dt))
         out["wall_s"] = time.perf_counter() - t0
         self.step_wall_s.append(out["wall_s"])   # host wall time of every session call (not a statistics key of the reference)
+        # The CONTROLLER's latency: the reference charges the time around solver.solve only (mpc_controller.py:234-236).  Simulating the plant
+        # is not controller time -- fed back as latency it adds plant steps, which add wall time (the payload plant is several times as
+        # expensive per step) -- so the plant launch's device time is taken out of the call's wall time, and an advance-only call counts nothing.
+        out["latency_s"] = max(0.0, out["wall_s"] - 1e-6 * out.get("plant_us", 0.0)) if plan else 0.0
         if plan and hyp is not None:
             self.force_estimator.update(out["best"], np.asarray(out["errors"]), alpha=0.6, beta=0.5)
         return out
@@ -203,7 +207,7 @@ class MPC_GATO:
                 break
             window = fig8[k0: k0 + self.N]
             out = self._step(True, True, nsteps, sim_dt, window, latency)
-            latency = out["wall_s"] if solve_time_override is None else float(solve_time_override)
+            latency = out["latency_s"] if solve_time_override is None else float(solve_time_override)
             x = np.asarray(out["x"], np.float64)
             ee = np.asarray(out["ee"], np.float64)
             log.add(timestamps=clock.now, solve_times=out["solve_us"] / 1000.0, goal_distances=float(np.linalg.norm(ee - window[1, :3])), ee_actual=ee,
@@ -253,7 +257,7 @@ class MPC_GATO:
                     break
                 window, since = window_of(goals[cur]), clock.now
             out = self._step(False, True, 0, sim_dt, window, latency)
-            latency = (at["wall_s"] + out["wall_s"]) if solve_time_override is None else float(solve_time_override)
+            latency = out["latency_s"] if solve_time_override is None else float(solve_time_override)   # the advance-only call is plant simulation
             log.add(timestamps=clock.now, solve_times=out["solve_us"] / 1000.0, goal_distances=dist, ee_actual=ee, joint_positions=x[: self.nq_robot],
                     joint_velocities=x[self.nq_robot:], best_trajectory_id=out["best"])
             if self.track_full_stats:

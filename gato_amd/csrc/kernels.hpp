@@ -3567,8 +3567,8 @@ __global__ __launch_bounds__(256) void ee_pos_kernel(float* __restrict__ out, co
 // =========================================================================================================================
 // rows := warm start (x0 repeated over the knots, zero controls: common.py:93-99), best := the same, state := x0
 template<class M>
-__global__ __launch_bounds__(256) void mpc_warm_kernel(float* __restrict__ xu, float* __restrict__ xu_best, float* __restrict__ x, const float* __restrict__ x0,
-                                                       int traj, int B)
+__global__ __launch_bounds__(256) void mpc_warm_kernel(float* __restrict__ xu, float* __restrict__ xu_best, float* __restrict__ x, float* __restrict__ x_last,
+                                                       const float* __restrict__ x0, int traj, int B)
 {
     constexpr int NX = 2 * M::NQ, KS = 3 * M::NQ;
     const int b = blockIdx.x;   // b == B: the best-trajectory buffer and the state
@@ -3577,10 +3577,14 @@ __global__ __launch_bounds__(256) void mpc_warm_kernel(float* __restrict__ xu, f
         const int o = i % KS;
         dst[i] = o < NX ? x0[o] : 0.f;
     }
-    if (b == B && threadIdx.x < NX) x[threadIdx.x] = x0[threadIdx.x];
+    // x_last := x0 as well: a selection issued before any plant step compares against the state the session started from
+    // (mpc_controller.py:196 takes x_last = x_curr at the top of every loop iteration), never against uninitialised memory
+    if (b == B && threadIdx.x < NX) { x[threadIdx.x] = x0[threadIdx.x]; x_last[threadIdx.x] = x0[threadIdx.x]; }
 }
 
-// x_last := x; x := the plant after nsteps RK4 steps of size h under the wrench fe6, step i driven by the control of knot
+// x_last := x (also when nsteps == 0: mpc_controller.py:196 takes x_last = x_curr at the top of EVERY loop iteration, so a step whose latency
+// rounds to no plant step scores the hypotheses against the current state, not a stale one); x := the plant after nsteps RK4 steps of size h
+// under the wrench fe6, step i driven by the control of knot
 // min(int(i / steps_per_knot), N - 1) of the best trajectory (mpc_controller.py:199-218; the quotient in double like the Python it mirrors)
 template<class M>
 __global__ __launch_bounds__(64) void mpc_plant_kernel(float* __restrict__ x, float* __restrict__ x_last, const float* __restrict__ xu_best,
@@ -3687,9 +3691,30 @@ __global__ __launch_bounds__(256) void reset_kernel(float* __restrict__ lambda, 
         for (uint32_t i = g; i < (uint32_t)B; i += T) { rho[i] = rho_init[i]; drho[i] = drho_init[i]; }
 }
 
+// it >= 0: entry `it`; it < 0: the first -it entries (the deferred form: the whole count vector after the last iteration)
 __global__ void add_remote_solved_kernel(uint32_t* __restrict__ global, const uint32_t* __restrict__ local, const uint32_t* __restrict__ remote, int it)
 {
-    if (blockIdx.x == 0 && threadIdx.x == 0) global[it] = local[it] + remote[it];
+    if (blockIdx.x != 0) return;
+    if (it >= 0) {
+        if (threadIdx.x == 0) global[it] = local[it] + remote[it];
+    } else {
+        for (int i = threadIdx.x; i < -it; i += blockDim.x) global[i] = local[i] + remote[i];
+    }
+}
+
+// what a solve changes for good -- the iterates, the duals, rho and drho -- copied aside in ONE launch at the start of a speculative (deferred-
+// count) sharded solve, so that it can be re-run exactly if some iteration's whole-batch count turns out to have reached the exit threshold
+__global__ __launch_bounds__(256) void snapshot_kernel(float* __restrict__ sx, const float* __restrict__ xu, uint32_t nxu, float* __restrict__ sl,
+                                                       const float* __restrict__ lambda, uint32_t nl, float* __restrict__ sr, const float* __restrict__ rho,
+                                                       const float* __restrict__ drho, uint32_t B)
+{
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x, T = gridDim.x * blockDim.x;
+    // both arrays start 256-byte aligned (hipMalloc / torch allocations); tails by the float
+    for (uint32_t i = g; i < nxu / 4; i += T) reinterpret_cast<real4*>(sx)[i] = reinterpret_cast<const real4*>(xu)[i];
+    for (uint32_t i = 4 * (nxu / 4) + g; i < nxu; i += T) sx[i] = xu[i];
+    for (uint32_t i = g; i < nl / 4; i += T) reinterpret_cast<real4*>(sl)[i] = reinterpret_cast<const real4*>(lambda)[i];
+    for (uint32_t i = 4 * (nl / 4) + g; i < nl; i += T) sl[i] = lambda[i];
+    for (uint32_t i = g; i < B; i += T) { sr[i] = rho[i]; sr[B + i] = drho[i]; }
 }
 
 // the end of a session step in ONE launch: best trajectory := row *best of the batch (the winner of select_best_kernel; row 0 without a

@@ -258,6 +258,7 @@ class PyBSQP {
         r["ee"] = ee;
         r["best"] = (int)io.best;
         r["solve_us"] = io.solve_us;
+        r["plant_us"] = io.plant_us;
         r["errors"] = err;
         return r;
     }

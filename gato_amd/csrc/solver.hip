@@ -74,6 +74,8 @@ struct GatoSolver {
     int32_t* d_order;
     int merit_in_step_forced;   // GATO_MERIT_IN_STEP = 0 / 1, else -1
     int linear_solver;  // 0: PCG (the reference's solver, pcg.cuh), 1: direct block-tridiagonal sweep (gato_set_linear_solver)
+    int direct_cr_forced;   // GATO_DIRECT_CR = 0 / 1 (read ONCE, when the solver is created), else -1: direct_uses_cr decides
+    bool cr_granted;        // the cyclic-reduction kernels' LDS has been granted on THIS handle's device (gato_set_linear_solver)
     // optional hipGraph replay of the host-buffer solve (gato_set_graph_mode): the fixed launch sequence of one solve captured once per
     // (dt, iteration count, mode switches) on the solver's own stream -- the buffers of gato_solve are the solver's own, so the kernel
     // arguments never change between solves
@@ -92,7 +94,7 @@ struct GatoSolver {
     float* d_mpc_pend;                     // the plant's swinging payload [quat | w | mass, length, damping, inertia] (gato_mpc_set_payload)
     bool mpc_payload = false;
     float *h_mpc_in = nullptr, *h_mpc_out = nullptr;   // pinned mirrors of [wrench | window | hypotheses] and [record | errors]: one copy each way per step
-    hipEvent_t mpc_ev0, mpc_ev1;
+    hipEvent_t mpc_ev0, mpc_ev1, mpc_ev2, mpc_ev3;   // around the solve | around the plant kernel
     bool mpc_begun = false;
     // sharded batch (gato_comm_init): this solver holds rows [rank B, (rank + 1) B) of a batch of global_batch trajectories
     void* comm = nullptr;              // ncclComm_t
@@ -100,6 +102,15 @@ struct GatoSolver {
     long global_batch = 0;             // 0: not sharded
     uint32_t* d_ns_local = nullptr;    // this rank's own counts (in the per-solve slab)
     uint32_t* d_ns_remote = nullptr;   // test hook: the other shards' solved counts per iteration (gato_debug_set_remote_solved)
+    // how a sharded solve learns the whole batch's solved count (gato_set_solved_count_mode):
+    //   deferred (default): the solve runs SPECULATIVELY as if the exit rule never fired, counting its own rows; ONE reduction of the count
+    //   vector at its end; only if some iteration's whole-batch count reached the threshold (never on workloads where nothing converges) the
+    //   snapshot taken at the start is restored and the solve re-run with ...   per-iteration: ... one 4-byte reduction per SQP iteration
+    int deferred_count = 1;
+    float thresh_override = -1.f;      // >= 0: what exit_threshold() returns (the speculative run: +inf)
+    float *d_snap_xu = nullptr, *d_snap_lambda = nullptr, *d_snap_rho = nullptr;   // snapshot of what a solve changes for good: xu | lambda | rho, drho
+    uint32_t* h_counts = nullptr;      // pinned: the reduced count vector, read by the host for the verdict
+    uint64_t n_replays = 0, n_deferred = 0;   // statistics: speculative solves run / of those replayed (gato_get_shard_stats)
     size_t plant_cap;
     uint32_t max_iters_alloc;
     Buffers bf;
@@ -158,6 +169,9 @@ static int create_impl(GatoSolver* s, int plant, int N, int B, const GatoParams*
     s->cw = Costs{params->q_cost, params->qd_cost, params->u_cost, params->N_cost, params->q_lim_cost, params->vel_lim_cost, params->ctrl_lim_cost};
     s->adapt_rho = 1;
     s->linear_solver = 0;
+    s->deferred_count = getenv("GATO_SOLVED_COUNT") ? (strcmp(getenv("GATO_SOLVED_COUNT"), "periter") != 0 ? 1 : 0) : 1;
+    s->direct_cr_forced = getenv("GATO_DIRECT_CR") ? (atoi(getenv("GATO_DIRECT_CR")) != 0 ? 1 : 0) : -1;
+    s->cr_granted = false;
     s->graph_mode = getenv("GATO_GRAPH") ? atoi(getenv("GATO_GRAPH")) : 0;
     s->own_stream = nullptr;
     s->graph_exec = nullptr;
@@ -220,7 +234,7 @@ static int create_impl(GatoSolver* s, int plant, int N, int B, const GatoParams*
     s->ee_cap = 0;
     s->d_plant = nullptr;
     s->plant_cap = 0;
-    s->mpc_ev0 = s->mpc_ev1 = nullptr;
+    s->mpc_ev0 = s->mpc_ev1 = s->mpc_ev2 = s->mpc_ev3 = nullptr;
     // per-trajectory defaults (bsqp.cuh:48-58)
     s->h_rho_init.assign(B, params->rho);
     s->h_drho_init.assign(B, 1.0f);
@@ -280,10 +294,13 @@ extern "C" int gato_destroy(GatoSolver* s)
     if (s->d_ee_out) (void)hipFree(s->d_ee_out);
     if (s->d_plant) (void)hipFree(s->d_plant);
     if (s->graph_exec) (void)hipGraphExecDestroy(s->graph_exec);
+    if (s->h_counts) (void)hipHostFree(s->h_counts);
     if (s->h_mpc_in) (void)hipHostFree(s->h_mpc_in);
     if (s->h_mpc_out) (void)hipHostFree(s->h_mpc_out);
     if (s->mpc_ev0) (void)hipEventDestroy(s->mpc_ev0);
     if (s->mpc_ev1) (void)hipEventDestroy(s->mpc_ev1);
+    if (s->mpc_ev2) (void)hipEventDestroy(s->mpc_ev2);
+    if (s->mpc_ev3) (void)hipEventDestroy(s->mpc_ev3);
     if (s->own_stream) (void)hipStreamDestroy(s->own_stream);
     for (void* p : s->allocs) (void)hipFree(p);
     for (hipEvent_t e : s->events) (void)hipEventDestroy(e);
@@ -294,7 +311,8 @@ extern "C" int gato_destroy(GatoSolver* s)
 // ---- launches ---------------------------------------------------------------------------------------------------------
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 // num_solved >= BatchSize * solve_ratio (bsqp.cuh:165), BatchSize = the WHOLE batch when it is sharded over ranks
-static inline float exit_threshold(const GatoSolver* s) { return (float)(s->global_batch > 0 ? s->global_batch : (long)s->B) * s->p.solve_ratio; }
+static inline float exit_threshold_exact(const GatoSolver* s) { return (float)(s->global_batch > 0 ? s->global_batch : (long)s->B) * s->p.solve_ratio; }
+static inline float exit_threshold(const GatoSolver* s) { return s->thresh_override >= 0.f ? s->thresh_override : exit_threshold_exact(s); }
 
 // out2 / zero: only for the first launch of a solve (merit of the initial iterate): second copy of the merits, slab to clear
 template<class M> static void launch_merit(GatoSolver* s, hipStream_t st, int na, float dt, int use_dz, int sqp_iter, float* out, float* out2 = nullptr,
@@ -570,24 +588,34 @@ template<class M> static void launch_pcg(GatoSolver* s, hipStream_t st, int sqp_
 // GATO_DIRECT_CR = 0 / 1 forces the choice.
 static bool direct_uses_cr(const GatoSolver* s)
 {
-    const char* e = getenv("GATO_DIRECT_CR");
-    if (e) return atoi(e) != 0;
+    if (s->direct_cr_forced >= 0) return s->direct_cr_forced != 0;
     if (s->N < 8) return false;
     if (s->N >= 64) return true;
     const long waves = (long)s->B * (s->N >= 32 ? 16 : (s->N >= 16 ? 8 : 4));
     return waves <= (long)s->cus * 16;   // every workgroup resident at once, four wavefronts per SIMD
 }
+// the LDS tier of btd_cr_kernel: [L | D | D^-1 | C][16][nx^2] + g [16][nx]
+template<class M> static constexpr size_t cr_lds() { return (size_t)(4 * 16 * (2 * M::NQ) * (2 * M::NQ) + 16 * (2 * M::NQ)) * sizeof(float); }
+// The kernel's static tiles + this tier exceed the 64 KB a kernel gets unasked, so the tier is asked for -- per FUNCTION AND DEVICE
+// (hipFuncSetAttribute acts on the current device): once per handle, on the handle's device, with the status checked, when the direct mode
+// is selected (gato_set_linear_solver).  Round 3 granted it once per process behind a function-local static and ignored the status: a host
+// that drives two GPUs from one process (DeviceGuard) got a failed launch on the second device, reported an iteration later.
+template<class M> static int grant_direct(GatoSolver* s)
+{
+    if (s->cr_granted) return GATO_OK;
+    auto grant = [](const void* fn, size_t bytes) { return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess; };
+    bool ok = grant(reinterpret_cast<const void*>(&btd_cr_kernel<M, 4>), cr_lds<M>()) && grant(reinterpret_cast<const void*>(&btd_cr_kernel<M, 8>), cr_lds<M>());
+    if (!kDouble) ok = ok && grant(reinterpret_cast<const void*>(&btd_cr_kernel<M, 16>), cr_lds<M>());   // (never launched by the float64 build)
+    if (!ok) {
+        (void)hipGetLastError();
+        return fail(GATO_ERR_HIP, "the direct solver's cyclic-reduction kernel was refused its LDS on this device (hipFuncSetAttribute)");
+    }
+    s->cr_granted = true;
+    return GATO_OK;
+}
 template<class M, int WAVES> static void launch_cr(GatoSolver* s, hipStream_t st, int sqp_iter)
 {
-    constexpr int NX = 2 * M::NQ;
-    const size_t lds = (size_t)(4 * 16 * NX * NX + 16 * NX) * sizeof(float);   // the LDS tier: [L | D | D^-1 | C][16][nx^2] + g [16][nx]
-    static bool granted = false;   // per instantiation (plant x wavefronts); the static tiles + this exceed the 64 KB a kernel gets unasked
-    bool& ok = granted;
-    if (!ok) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&btd_cr_kernel<M, WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        ok = true;
-    }
-    hipLaunchKernelGGL((btd_cr_kernel<M, WAVES>), dim3(s->B), dim3(64 * WAVES), lds, st, s->bf, s->N, s->B, sqp_iter);
+    hipLaunchKernelGGL((btd_cr_kernel<M, WAVES>), dim3(s->B), dim3(64 * WAVES), cr_lds<M>(), st, s->bf, s->N, s->B, sqp_iter);
 }
 template<class M> static void launch_direct(GatoSolver* s, hipStream_t st, int sqp_iter)
 {
@@ -714,8 +742,28 @@ static int reduce_solved(GatoSolver* s, hipStream_t st, int it)
     }
     return GATO_OK;
 }
+// A captured solve (gato_set_graph_mode) has the sharding state baked in: the exit threshold, the array the exit rule reads, the
+// per-iteration collective / add_remote_solved nodes and the communicator itself.  Whatever changes any of them drops the graph; the next
+// gato_solve captures again (a stale graph would apply the unsharded rule without an error, or launch on a destroyed communicator).
+static void drop_graph(GatoSolver* s)
+{
+    if (s->graph_exec) { (void)hipGraphExecDestroy(s->graph_exec); s->graph_exec = nullptr; }
+}
+// the deferred form: after the LAST iteration of a speculative solve, the whole count vector in one reduction
+static int reduce_solved_all(GatoSolver* s, hipStream_t st, int iters)
+{
+    if (s->comm) {
+        NCCLCHK(g_rccl.AllReduce(s->d_ns_local, s->bf.num_solved, (size_t)iters, ncclUint32, ncclSum, (ncclComm_t)s->comm, st));
+    } else if (s->d_ns_remote) {
+        hipLaunchKernelGGL(add_remote_solved_kernel, dim3(1), dim3(64), 0, st, s->bf.num_solved, (const uint32_t*)s->d_ns_local, (const uint32_t*)s->d_ns_remote, -iters);
+    } else {
+        return fail(GATO_ERR_INVALID, "sharded solver without a communicator");
+    }
+    return GATO_OK;
+}
 static void set_sharded(GatoSolver* s, long global_batch)
 {
+    drop_graph(s);
     s->global_batch = global_batch;
     s->bf.num_solved_w = global_batch > 0 ? s->d_ns_local : s->bf.num_solved;
 }
@@ -758,6 +806,7 @@ extern "C" int gato_comm_destroy(GatoSolver* s)
     GUARD(s);
     int rc = sync_last(s);
     if (rc) return rc;
+    drop_graph(s);
     if (s->comm) {
         NCCLCHK(g_rccl.CommDestroy((ncclComm_t)s->comm));
         s->comm = nullptr;
@@ -801,16 +850,14 @@ extern "C" int gato_debug_set_remote_solved(GatoSolver* s, const uint32_t* per_i
     return GATO_OK;
 }
 
-template<class M> static int solve_impl(GatoSolver* s, float* d_xu, float dt, const float* d_xs, const float* d_ref, hipStream_t st)
+// the launch sequence of one solve on `st`.  per_iter_count: a sharded solve shares the solved count after every PCG launch (the exact,
+// fully asynchronous form); otherwise the kernels read whatever exit_threshold() says (the unsharded rule, or +inf in a speculative run)
+template<class M> static int enqueue_solve(GatoSolver* s, float dt, hipStream_t st, uint32_t iters, bool per_iter_count)
 {
     Buffers& bf = s->bf;
     const int B = s->B;
-    bf.xu = d_xu; bf.x_s = d_xs; bf.ref = d_ref;
-    s->last_stream = st;
-    s->last_stream_valid = true;
     size_t ei = 0;
     mark(s, st, -1, ei);
-    const uint32_t iters = s->p.max_sqp_iters <= s->max_iters_alloc ? s->p.max_sqp_iters : s->max_iters_alloc;
     // bsqp.cuh:112-118: the merit of the initial iterate (kept twice: running merit and merit_initial0) and the clearing of dz,
     // pcg_iters, converged, ctrl, num_solved (the slab is a multiple of 64 words) -- inside the first step / first assembly launch
     // where the plan allows it, otherwise ONE launch ahead of the loop
@@ -836,7 +883,7 @@ template<class M> static int solve_impl(GatoSolver* s, float* d_xu, float dt, co
             mark(s, st, ST_SCHUR, ei);
             launch_pcg<M>(s, st, (int)it);
         }
-        if (s->global_batch > 0) {
+        if (per_iter_count) {
             const int rc_r = reduce_solved(s, st, (int)it);
             if (rc_r != GATO_OK) return rc_r;
         }
@@ -863,9 +910,56 @@ template<class M> static int solve_impl(GatoSolver* s, float* d_xu, float dt, co
     return GATO_OK;
 }
 
-static int solve_dispatch(GatoSolver* s, float* d_xu, float dt, const float* d_xs, const float* d_ref, hipStream_t st)
+// async_only: the caller cannot take a host synchronisation inside the solve (stream capture): a sharded solve then shares the count per iteration
+template<class M> static int solve_impl(GatoSolver* s, float* d_xu, float dt, const float* d_xs, const float* d_ref, hipStream_t st, bool async_only = false)
 {
-    return s->plant == GATO_PLANT_INDY7 ? solve_impl<Indy7>(s, d_xu, dt, d_xs, d_ref, st) : solve_impl<Iiwa14>(s, d_xu, dt, d_xs, d_ref, st);
+    Buffers& bf = s->bf;
+    const int B = s->B;
+    bf.xu = d_xu; bf.x_s = d_xs; bf.ref = d_ref;
+    s->last_stream = st;
+    s->last_stream_valid = true;
+    const uint32_t iters = s->p.max_sqp_iters <= s->max_iters_alloc ? s->p.max_sqp_iters : s->max_iters_alloc;
+    const bool sharded = s->global_batch > 0;
+    if (!sharded) return enqueue_solve<M>(s, dt, st, iters, false);
+    if (!s->deferred_count || async_only || iters == 0) return enqueue_solve<M>(s, dt, st, iters, true);
+    // ---- deferred: the solved count is the ONLY coupling between the shards (bsqp.cuh:165) and on every workload where trajectories do not
+    // converge it never changes anything -- ten small-message all-reduces on the critical path of every solve for nothing.  So: snapshot what a
+    // solve changes for good, run it as if the rule never fired (own rows counted), reduce the whole count vector ONCE, let the host look at it.
+    if (!s->d_snap_xu) {
+        int rc;
+        if ((rc = dalloc(s, &s->d_snap_xu, (size_t)B * s->traj, false)) != GATO_OK) return rc;
+        if ((rc = dalloc(s, &s->d_snap_lambda, (size_t)B * s->vecp, false)) != GATO_OK) return rc;
+        if ((rc = dalloc(s, &s->d_snap_rho, 2 * (size_t)B, false)) != GATO_OK) return rc;
+        HIPCHK(hipHostMalloc((void**)&s->h_counts, s->max_iters_alloc * sizeof(uint32_t), hipHostMallocDefault));
+    }
+    const size_t bx = (size_t)B * s->traj * sizeof(float), bl = (size_t)B * s->vecp * sizeof(float), bb = (size_t)B * sizeof(float);
+    hipLaunchKernelGGL(snapshot_kernel, dim3(s->cus > 0 ? s->cus * 4 : 256), dim3(256), 0, st, s->d_snap_xu, (const float*)d_xu, (uint32_t)(bx / sizeof(float)),
+                       s->d_snap_lambda, (const float*)bf.lambda, (uint32_t)(bl / sizeof(float)), s->d_snap_rho, (const float*)bf.rho, (const float*)bf.drho, (uint32_t)B);
+    s->thresh_override = INFINITY;
+    int rc = enqueue_solve<M>(s, dt, st, iters, false);
+    s->thresh_override = -1.f;
+    if (rc != GATO_OK) return rc;
+    rc = reduce_solved_all(s, st, (int)iters);
+    if (rc != GATO_OK) return rc;
+    HIPCHK(hipMemcpyAsync(s->h_counts, bf.num_solved, iters * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));   // the one host wait of a deferred solve: the verdict must be known before anyone consumes the results
+    s->n_deferred++;
+    const float thresh = exit_threshold_exact(s);
+    bool fired = false;
+    for (uint32_t i = 0; i < iters; i++) fired = fired || (float)s->h_counts[i] >= thresh;
+    if (!fired) return GATO_OK;
+    // some iteration's whole-batch count reached the threshold: the speculative run went past the exit.  Back to the snapshot and again, exactly.
+    s->n_replays++;
+    HIPCHK(hipMemcpyAsync(d_xu, s->d_snap_xu, bx, hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipMemcpyAsync(bf.lambda, s->d_snap_lambda, bl, hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipMemcpyAsync(bf.rho, s->d_snap_rho, bb, hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipMemcpyAsync(bf.drho, s->d_snap_rho + B, bb, hipMemcpyDeviceToDevice, st));
+    return enqueue_solve<M>(s, dt, st, iters, true);
+}
+
+static int solve_dispatch(GatoSolver* s, float* d_xu, float dt, const float* d_xs, const float* d_ref, hipStream_t st, bool async_only = false)
+{
+    return s->plant == GATO_PLANT_INDY7 ? solve_impl<Indy7>(s, d_xu, dt, d_xs, d_ref, st, async_only) : solve_impl<Iiwa14>(s, d_xu, dt, d_xs, d_ref, st, async_only);
 }
 
 static void collect_profile(GatoSolver* s)
@@ -910,7 +1004,7 @@ extern "C" int gato_solve(GatoSolver* s, float* xu, float dt, const float* x_s, 
             if (s->graph_exec) { (void)hipGraphExecDestroy(s->graph_exec); s->graph_exec = nullptr; }
             hipGraph_t g = nullptr;
             HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-            const int rc_c = solve_dispatch(s, s->d_xu_own, dt, s->d_xs_own, s->d_ref_own, st);
+            const int rc_c = solve_dispatch(s, s->d_xu_own, dt, s->d_xs_own, s->d_ref_own, st, true);   // no host wait inside a capture
             const hipError_t e_c = hipStreamEndCapture(st, &g);
             if (rc_c != GATO_OK) { if (g) (void)hipGraphDestroy(g); return rc_c; }
             if (e_c != hipSuccess) return fail(GATO_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e_c));
@@ -1090,6 +1184,20 @@ extern "C" int gato_copy_final_merit_device(GatoSolver* s, float* d_out, void* s
     HIPCHK(hipMemcpyAsync(d_out, s->bf.merit_cur, s->B * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return GATO_OK;
 }
+extern "C" int gato_set_solved_count_mode(GatoSolver* s, int mode)
+{
+    if (!s) return fail(GATO_ERR_INVALID, "null solver");
+    if (mode != GATO_COUNT_DEFERRED && mode != GATO_COUNT_PER_ITERATION) return fail(GATO_ERR_INVALID, "unknown solved-count mode (0 = per iteration, 1 = deferred)");
+    s->deferred_count = mode == GATO_COUNT_DEFERRED ? 1 : 0;
+    return GATO_OK;
+}
+extern "C" int gato_get_shard_stats(GatoSolver* s, uint64_t* deferred_solves, uint64_t* replays)
+{
+    if (!s) return fail(GATO_ERR_INVALID, "null solver");
+    if (deferred_solves) *deferred_solves = s->n_deferred;
+    if (replays) *replays = s->n_replays;
+    return GATO_OK;
+}
 extern "C" int gato_set_graph_mode(GatoSolver* s, int enabled)
 {
     if (!s) return fail(GATO_ERR_INVALID, "null solver");
@@ -1100,6 +1208,11 @@ extern "C" int gato_set_linear_solver(GatoSolver* s, int mode)
 {
     if (!s) return fail(GATO_ERR_INVALID, "null solver");
     if (mode != GATO_LINSOLVE_PCG && mode != GATO_LINSOLVE_DIRECT) return fail(GATO_ERR_INVALID, "unknown linear solver (0 = PCG, 1 = direct)");
+    if (mode == GATO_LINSOLVE_DIRECT) {
+        GUARD(s);   // the grant is per device: the handle's
+        const int rc = s->plant == GATO_PLANT_INDY7 ? grant_direct<Indy7>(s) : grant_direct<Iiwa14>(s);
+        if (rc != GATO_OK) return rc;   // the solver stays on the linear solver it had
+    }
     s->linear_solver = mode;
     return GATO_OK;
 }
@@ -1301,7 +1414,7 @@ template<class M> static int mpc_begin_impl(GatoSolver* s, const float* x0)
 {
     hipStream_t st = s->own_stream;
     HIPCHK(hipMemcpyAsync(s->d_sel_xm, x0, s->nx * sizeof(float), hipMemcpyHostToDevice, st));   // staging for x0
-    hipLaunchKernelGGL((mpc_warm_kernel<M>), dim3(s->B + 1), dim3(256), 0, st, s->d_xu_own, s->d_mpc_best, s->d_mpc_x, (const float*)s->d_sel_xm, s->traj, s->B);
+    hipLaunchKernelGGL((mpc_warm_kernel<M>), dim3(s->B + 1), dim3(256), 0, st, s->d_xu_own, s->d_mpc_best, s->d_mpc_x, s->d_mpc_xlast, (const float*)s->d_sel_xm, s->traj, s->B);
     HIPCHK(hipMemsetAsync(s->bf.lambda, 0, (size_t)s->B * s->vecp * sizeof(float), st));         // reset_dual (mpc_controller.py:172)
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(st));
@@ -1313,7 +1426,10 @@ extern "C" int gato_mpc_begin(GatoSolver* s, const float* x0)
     GUARD(s);
     int rc = sync_last(s);
     if (rc) return rc;
-    if (!s->mpc_ev0) { HIPCHK(hipEventCreate(&s->mpc_ev0)); HIPCHK(hipEventCreate(&s->mpc_ev1)); }
+    if (!s->mpc_ev0) {
+        HIPCHK(hipEventCreate(&s->mpc_ev0)); HIPCHK(hipEventCreate(&s->mpc_ev1));
+        HIPCHK(hipEventCreate(&s->mpc_ev2)); HIPCHK(hipEventCreate(&s->mpc_ev3));
+    }
     if (!s->h_mpc_in) {
         HIPCHK(hipHostMalloc((void**)&s->h_mpc_in, (8 + 6 * (size_t)s->N + 6 * (size_t)s->B) * sizeof(float), hipHostMallocDefault));
         HIPCHK(hipHostMalloc((void**)&s->h_mpc_out, (20 + (size_t)s->B) * sizeof(float), hipHostMallocDefault));
@@ -1325,8 +1441,9 @@ extern "C" int gato_mpc_begin(GatoSolver* s, const float* x0)
 template<class M> static int mpc_step_impl(GatoSolver* s, GatoMpcStep* io)
 {
     hipStream_t st = s->own_stream;
-    const bool advance = (io->phases & GATO_MPC_ADVANCE) != 0 && io->plant_steps > 0, plan = (io->phases & GATO_MPC_PLAN) != 0;
-    if (advance && !(io->steps_per_knot > 0.0)) return fail(GATO_ERR_INVALID, "steps_per_knot must be positive");
+    // ADVANCE with plant_steps == 0 still runs the plant launch: it is what takes x_last := x (mpc_controller.py:196-197, every loop iteration)
+    const bool advance = (io->phases & GATO_MPC_ADVANCE) != 0, plan = (io->phases & GATO_MPC_PLAN) != 0;
+    if (advance && io->plant_steps > 0 && !(io->steps_per_knot > 0.0)) return fail(GATO_ERR_INVALID, "steps_per_knot must be positive");
     if (plan && !io->ref_window) return fail(GATO_ERR_INVALID, "ref_window is required for GATO_MPC_PLAN");
     // ONE host-to-device copy from pinned memory: [wrench | reference window | hypotheses] (only as far as this step needs)
     {
@@ -1340,9 +1457,12 @@ template<class M> static int mpc_step_impl(GatoSolver* s, GatoMpcStep* io)
         }
         if (advance || plan) HIPCHK(hipMemcpyAsync(s->d_mpc_fw, s->h_mpc_in, n * sizeof(float), hipMemcpyHostToDevice, st));
     }
-    if (advance)
+    if (advance) {
+        HIPCHK(hipEventRecord(s->mpc_ev2, st));
         hipLaunchKernelGGL((mpc_plant_kernel<M>), dim3(1), dim3(64), 0, st, s->d_mpc_x, s->d_mpc_xlast, (const float*)s->d_mpc_best, (const float*)s->d_mpc_fw,
-                           (int)io->plant_steps, io->sim_dt, io->steps_per_knot, s->N, s->mpc_payload ? s->d_mpc_pend : (float*)nullptr);
+                           (int)io->plant_steps, io->sim_dt, io->plant_steps > 0 ? io->steps_per_knot : 1.0, s->N, s->mpc_payload ? s->d_mpc_pend : (float*)nullptr);
+        HIPCHK(hipEventRecord(s->mpc_ev3, st));
+    }
     const bool selecting = plan && io->select && s->B > 1;
     if (plan) {
         hipLaunchKernelGGL((mpc_prepare_kernel<M>), dim3(s->B), dim3(256), 0, st, s->d_xu_own, s->d_xs_own, s->d_ref_own, s->bf.f_ext, (const float*)s->d_mpc_best,
@@ -1376,6 +1496,12 @@ template<class M> static int mpc_step_impl(GatoSolver* s, GatoMpcStep* io)
     for (int i = 0; i < 3; i++) io->ee[i] = rec[s->nx + i];
     io->best = plan ? (int32_t)rec[s->nx + 3] : 0;
     io->solve_us = 0.0;
+    io->plant_us = 0.0;
+    if (advance) {
+        f32_t ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, s->mpc_ev2, s->mpc_ev3));
+        io->plant_us = (double)ms * 1e3;
+    }
     if (plan) {
         f32_t ms = 0;
         HIPCHK(hipEventElapsedTime(&ms, s->mpc_ev0, s->mpc_ev1));

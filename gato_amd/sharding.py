@@ -4,8 +4,10 @@ Rank r solves rows [r*B_local, (r+1)*B_local) of the global batch with its own s
 cross ranks:
 
 * the SOLVED COUNT of the exit rule (bsqp.cuh:165) -- the only coupling between trajectories.  `connect()` gives the rank's solver a native RCCL
-  communicator (`gato_comm_init`, include/gato_abi.h) and every SQP iteration then carries one 4-byte ncclAllReduce of that count on the solve's
-  stream: every rank takes the exit of the WHOLE batch in the same iteration, for any solve_ratio.  That also covers solve_ratio = 1: a shard
+  communicator (`gato_comm_init`, include/gato_abi.h).  By default the count is DEFERRED (round 4): a solve runs speculatively as if the rule
+  never fired, ONE ncclAllReduce of the per-iteration count vector follows it, and only when some iteration's whole-batch count reached the
+  threshold is the solve restored from its snapshot and re-run with one 4-byte all-reduce per SQP iteration (`set_solved_count_mode`).  Either
+  way every rank takes the exit of the WHOLE batch in the same iteration, for any solve_ratio.  That also covers solve_ratio = 1: a shard
   whose rows have all converged keeps stepping them while another shard has not (converged trajectories are still moved by the line search,
   bsqp.cuh:165-171), exactly as the unsharded solver would -- per-shard counting would stop that shard early and make its iterates depend on
   the world size.  Without a communicator (`check_sharded_params`) only the case where nothing can converge differently is accepted: it is refused.
@@ -37,7 +39,20 @@ def connect(solver, group=None):
     the sharded batch.  The 128-byte id travels through torch.distributed (any backend); everything after that is RCCL inside the library."""
     import torch.distributed as dist
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    box = [solver.comm_unique_id() if rank == 0 else None]
+    # 1. agree that EVERY rank can open RCCL before any rank enters a collective of its own: creating an id proves librccl.so loads and
+    #    answers.  A rank that fails here must not leave the others blocked in the broadcast or inside ncclCommInitRank.
+    uid, err = None, None
+    try:
+        uid = solver.comm_unique_id()
+    except Exception as e:   # noqa: BLE001
+        err = "%s: %s" % (type(e).__name__, e)
+    flags = [None] * world
+    dist.all_gather_object(flags, err, group=group)
+    bad = {r: f for r, f in enumerate(flags) if f is not None}
+    if bad:
+        raise RuntimeError("RCCL is not available on rank(s) %s -- no rank initialises a communicator" % bad)   # raised on every rank alike
+    # 2. rank 0's id to everybody (rank 0 always broadcasts), then the collective initialisation
+    box = [uid if rank == 0 else None]
     dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
     solver.comm_init(box[0], world, rank)
     return solver

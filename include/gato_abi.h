@@ -168,6 +168,9 @@ typedef struct GatoMpcStep {
     int32_t best;            /* selected row */
     double solve_us;         /* device time of the SQP solve (hipEvents around its launches); 0 without PLAN */
     gato_real* errors;       /* [B] host or NULL: the selection's per-hypothesis errors */
+    double plant_us;         /* out: device time of the plant simulation (hipEvents around its launch); 0 without ADVANCE.  SIMULATING the plant
+                              * is not controller latency: a loop that feeds measured latency back (mpc_controller.py:234-236 charges the time
+                              * around solver.solve only) subtracts this from the wall time of the call */
 } GatoMpcStep;
 /* state := x0 ([nx] host); every row and the best trajectory := warm start (x0 over the knots, zero controls: common.py:93-99); reset_dual */
 int gato_mpc_begin(GatoSolver* s, const gato_real* x0);
@@ -211,6 +214,19 @@ int gato_comm_unique_id(char* out128);
 int gato_comm_init(GatoSolver* s, const char* id128, int world_size, int rank, int64_t global_batch);
 int gato_comm_destroy(GatoSolver* s);
 int gato_gather_results(GatoSolver* s, const gato_real* d_local, gato_real* d_all, uint64_t count, void* stream);
+/* How a sharded solve learns the whole batch's solved count (the exit rule of bsqp.cuh:165 is the only coupling between the shards):
+ *   GATO_COUNT_DEFERRED (default)   the solve runs speculatively as if the rule never fired, every rank counting its own rows; ONE
+ *       all-reduce of the [max_sqp_iters] count vector at its end, then the host looks at it (gato_solve_device therefore returns only when
+ *       a sharded solve has finished).  Only if some iteration's whole-batch count reached batch x solve_ratio -- never on workloads whose
+ *       trajectories do not converge -- the snapshot taken at the start (xu, lambda, rho, drho) is restored and the solve re-run with the
+ *       per-iteration reduction: the results are those of the unsharded solver either way, bit for bit.
+ *   GATO_COUNT_PER_ITERATION        one 4-byte all-reduce between the PCG launch and the step launch of every SQP iteration, no host wait
+ *       (round 3's form; also what a hipGraph capture of a sharded solve uses).
+ * gato_get_shard_stats: speculative solves run so far, and how many of them had to be replayed. */
+#define GATO_COUNT_PER_ITERATION 0
+#define GATO_COUNT_DEFERRED 1
+int gato_set_solved_count_mode(GatoSolver* s, int mode);
+int gato_get_shard_stats(GatoSolver* s, uint64_t* deferred_solves, uint64_t* replays);
 /* TEST HOOK: a shard of a global_batch-trajectory batch WITHOUT a communicator: the other shards' solved counts per SQP iteration are given
  * (global_batch = 0 ends it).  Lets a 1-GPU box check the sharded exit rule against the unsharded solve. */
 int gato_debug_set_remote_solved(GatoSolver* s, const uint32_t* per_iter, int n, int64_t global_batch);

@@ -124,3 +124,23 @@ int main() {
     subprocess.check_call(["g++", "-std=c++17", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe), LIB, "-Wl,-rpath," + os.path.dirname(LIB)])
     env = dict(os.environ)
     assert subprocess.call([str(exe)], env=env) == 0
+
+
+def test_direct_solver_lds_grant_is_per_handle_and_checked(lib):
+    """Round-3 review: launch_cr granted its LDS once per PROCESS (function-local static) and ignored hipFuncSetAttribute's status, so the second
+    device of a two-GPU host got a failed launch an iteration later.  The two-device case cannot run on this pool; what can be checked here is
+    that the status path exists: the grant lives on the handle (per device), happens where the direct mode is selected, and a refusal is an error
+    return of gato_set_linear_solver -- and that the entry point rejects what it must without a device."""
+    src = open(os.path.join(ROOT, "gato_amd", "csrc", "solver.hip")).read()
+    launch_cr = src[src.index("static void launch_cr("):]
+    launch_cr = launch_cr[:launch_cr.index("\n}\n")]
+    assert "static bool" not in launch_cr and "hipFuncSetAttribute" not in launch_cr          # no per-process flag, no unchecked grant at launch time
+    grant = src[src.index("static int grant_direct("):]
+    grant = grant[:grant.index("\n}\n")]
+    assert "s->cr_granted" in grant and "GATO_ERR_HIP" in grant and "== hipSuccess" in grant   # per handle, status checked, error returned
+    setter = src[src.index('extern "C" int gato_set_linear_solver('):]
+    setter = setter[:setter.index("\n}\n")]
+    assert "grant_direct<" in setter and "GUARD(s)" in setter and setter.index("grant_direct<") < setter.index("s->linear_solver = mode")
+    lib.gato_set_linear_solver.argtypes = [C.c_void_p, C.c_int]
+    assert lib.gato_set_linear_solver(None, 1) != 0
+    assert "GATO_DIRECT_CR" not in src[src.index("static bool direct_uses_cr("):src.index("template<class M> static constexpr size_t cr_lds()")]   # read once, at create

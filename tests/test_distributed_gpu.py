@@ -136,6 +136,13 @@ def test_one_rank_communicator_through_the_same_entry_points():
     r = s.solve(pr["xu"], 0.01, pr["x_s"], pr["ref"])
     for k in ("XU", "final_merit", "pcg_iters_all", "ls_step_size", "kkt_converged"):
         np.testing.assert_array_equal(r[k], plain[k], err_msg=k)
+    assert s.shard_stats() == {"deferred_solves": 1, "replays": 0}   # the default: ONE ncclAllReduce of the count vector behind the solve
+    s.set_solved_count_mode("per_iteration")                          # round 3's form: a 4-byte ncclAllReduce in every SQP iteration
+    s.reset_dual(); s.reset_rho()
+    r = s.solve(pr["xu"], 0.01, pr["x_s"], pr["ref"])
+    for k in ("XU", "final_merit", "pcg_iters_all", "ls_step_size", "kkt_converged"):
+        np.testing.assert_array_equal(r[k], plain[k], err_msg=k)
+    assert s.shard_stats() == {"deferred_solves": 1, "replays": 0}
     dev = torch.device("cuda", 0)
     pk = PackedResults(B, s.traj, 1, dev)
     pk.xu.copy_(torch.from_numpy(r["XU"]).to(dev))
@@ -150,12 +157,19 @@ def test_one_rank_communicator_through_the_same_entry_points():
         s.gather_results(pk.local.data_ptr(), out.data_ptr(), pk.n, 0)   # no communicator any more
 
 
+@pytest.mark.parametrize("mode", ["deferred", "per_iteration", "graph", "graph_recapture"])
 @pytest.mark.parametrize("ratio", [0.5, 1.0])
-def test_sharded_exit_rule_against_the_unsharded_solve(ratio):
+def test_sharded_exit_rule_against_the_unsharded_solve(ratio, mode):
     """bsqp.cuh:165 on a sharded batch, product path: the mixed batch of tests/mixed_batch.py cut in two shards (the first holds every early
     converger, the second none), each shard a NativeSolver that counts its own rows and is GIVEN the other shard's solved count per SQP
-    iteration (what the ncclAllReduce delivers on two GPUs): both shards exit in the whole batch's iteration and reproduce their rows of the
-    unsharded solve bit for bit -- also with solve_ratio 1, where the converged shard must keep stepping its rows."""
+    iteration (what the all-reduce delivers on two GPUs): both shards exit in the whole batch's iteration and reproduce their rows of the
+    unsharded solve bit for bit -- also with solve_ratio 1, where the converged shard must keep stepping its rows.
+    mode: how the count reaches the rule --
+      deferred        (round 4, the default) speculative solve + ONE reduction of the count vector; ratio 0.5 fires the rule: the REPLAY path
+                      (snapshot restored, exact re-run); ratio 1 never reaches the threshold: the NO-REPLAY path
+      per_iteration   one reduction per SQP iteration (round 3)
+      graph           hipGraph replay of the host-buffer solve captured while sharded (per-iteration reduction nodes inside the graph)
+      graph_recapture a graph captured UNSHARDED must not survive the switch to the sharded rule (advisor, round 3: the cache key ignored it)"""
     from gato_amd._lib import NativeSolver
     from gato_amd.bsqp.config import DEFAULT_SOLVER_PARAMS
     from mixed_batch import mixed_problem
@@ -174,12 +188,29 @@ def test_sharded_exit_rule_against_the_unsharded_solve(ratio):
         sh = mixed_problem("indy7", N, kinds=kinds, ee=ee, rows=(lo, hi))
         s = NativeSolver("indy7", N, hi - lo, dt=0.01, **p)
         s.set_f_ext_batch(sh["f_ext"]); s.set_cost_weights_batch(sh["w"])
+        if mode == "graph_recapture":
+            s.set_graph_mode(True)
+            first = s.solve(sh["xu"], 0.01, sh["x_s"], sh["ref"])      # captured with the UNSHARDED rule (a different solve: the shard alone)
+            assert np.all(np.isfinite(first["XU"]))
+            s.reset_dual(); s.reset_rho()
         s.debug_set_remote_solved(solved[:, other].sum(axis=1).astype(np.uint32), B)
+        if mode == "per_iteration":
+            s.set_solved_count_mode("per_iteration")
+        if mode == "graph":
+            s.set_graph_mode(True)
         r = s.solve(sh["xu"], 0.01, sh["x_s"], sh["ref"])
         assert r["iters_done"] == ref["iters_done"] and r["ls_num_iters"] == ref["ls_num_iters"]
         for k in ("XU", "final_merit", "kkt_converged", "sqp_iters"):
             np.testing.assert_array_equal(r[k], ref[k][lo:hi], err_msg=k)
         np.testing.assert_array_equal(r["pcg_iters_all"], ref["pcg_iters_all"][:, lo:hi])
+        np.testing.assert_array_equal(r["ls_step_size"], ref["ls_step_size"][:, lo:hi])
+        np.testing.assert_array_equal(s.read("rho"), one.read("rho")[lo:hi])
+        np.testing.assert_array_equal(s.read("lambda").reshape(hi - lo, -1), one.read("lambda").reshape(B, -1)[lo:hi])
+        st = s.shard_stats()
+        if mode == "deferred":   # the rule fires at ratio 0.5 (replay) and never at ratio 1 (the speculative run IS the result)
+            assert st == {"deferred_solves": 1, "replays": 1 if ratio == 0.5 else 0}, st
+        else:
+            assert st["deferred_solves"] == 0, st
     if ratio == 0.5:
         assert 2 <= ref["iters_done"] < 6
     else:

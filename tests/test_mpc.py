@@ -235,3 +235,38 @@ def test_closed_loop_goals():
     assert {"timestamps", "solve_times", "goal_distances", "ee_actual", "joint_positions", "joint_velocities", "best_trajectory_id", "goal_outcomes",
             "goal_reached_times", "time_to_all_reached", "sqp_iters", "pcg_iters"} == set(st)
     assert mpc.pendulum_state is None and not mpc.has_pendulum      # the payload is tests/test_pendulum.py
+
+
+@pytest.mark.gpu
+def test_session_selection_without_a_plant_step_scores_against_the_current_state():
+    """mpc_controller.py:196-197 takes x_last = x_curr at the top of EVERY loop iteration.  A session step whose latency rounds to no plant
+    step (the measured 0.15 ms step against sim_dt = 1 ms: most steps), and a selection issued before any plant step at all, must score the
+    hypotheses from the CURRENT state -- round 3 left x_last stale (never written without a plant step, uninitialised before the first one)."""
+    from gato_amd._lib import NativeSolver
+    plant, N, B, dt, sim_dt = "indy7", 8, 6, 0.01, 0.001
+    p = dict(DEFAULT_SOLVER_PARAMS, max_sqp_iters=1)
+    rng = np.random.default_rng(9)
+    x0 = np.concatenate([INDY7_START_CONFIGS["ready"], np.zeros(6)]).astype(np.float32)
+    fext = rng.normal(0, 3.0, (B, 6)).astype(np.float32)
+    wrench = np.array([0.0, 0.0, 0.0, 1.0, -2.0, 3.0], np.float32)
+    win = np.tile(np.array([0.3, 0.2, 0.7, 0, 0, 0], np.float32), (N, 1))
+    ses, man = NativeSolver(plant, N, B, dt=dt, **p), NativeSolver(plant, N, B, dt=dt, **p)
+    for s in (ses, man):
+        s.set_f_ext_batch(fext)
+    ses.mpc_begin(x0)
+    # (1) a selecting plan before ANY advance: x_last is the session's start state, u_last the warm start's zero control
+    out = ses.mpc_step(advance=False, plan=True, ref_window=win, select=True, select_dt=sim_dt)
+    best, err = man.select_best(x0, np.zeros(6, np.float32), x0, sim_dt)
+    np.testing.assert_array_equal(out["errors"], err)
+    assert out["best"] == best and np.all(np.isfinite(out["errors"]))
+    # (2) move the plant, then an ADVANCE with zero plant steps + a selection: x_last must be the state the plant is in NOW
+    a = ses.mpc_step(advance=True, plan=False, plant_steps=12, sim_dt=sim_dt, steps_per_knot=dt / sim_dt, plant_wrench=wrench)
+    x1 = a["x"].copy()
+    assert np.abs(x1 - x0).max() > 1e-4 and a["plant_us"] > 0
+    best_row = ses.mpc_best()
+    out = ses.mpc_step(advance=True, plan=True, plant_steps=0, sim_dt=sim_dt, steps_per_knot=dt / sim_dt, plant_wrench=wrench, ref_window=win, select=True,
+                       select_dt=sim_dt)
+    np.testing.assert_array_equal(out["x"], x1)
+    best, err = man.select_best(x1, best_row[12:18], x1, sim_dt)
+    np.testing.assert_array_equal(out["errors"], err)
+    assert out["best"] == best
