@@ -1569,6 +1569,35 @@ template<int NXT, int RPT, bool PACKED = true> GATO_DEV void rows_dot(const floa
     }
 }
 
+// nx % 4 != 0 (iiwa14, nx = 14): the LDS vectors keep every block at a stride of VS = 16 floats, so a row's window is three 16-byte
+// aligned blocks read with ds_read_b128 (4 per block: 12 loads per product) instead of 21 eight-byte reads that hipcc pairs into
+// ds_read2_b64 (half the LDS rate, twice the instructions).  Same association as rows_dot's nx % 4 != 0 form: ONE (even, odd) pair of
+// partial sums per row, advanced over the 3 nx / 2 column pairs in sequence -- the same bits.
+template<int NXT, int RPT, int VS> GATO_DEV void rows_dot_strided(const float (*rows)[3 * NXT], const float* __restrict__ win, float* acc)
+{
+    static_assert(NXT % 2 == 0 && VS % 4 == 0 && VS >= NXT, "blocks of whole pairs at a 16-byte stride");
+    f32x2 a2[RPT];
+#pragma unroll
+    for (int u = 0; u < RPT; u++) a2[u] = f32x2{0.f, 0.f};
+#pragma unroll
+    for (int blk = 0; blk < 3; blk++) {
+        float w[VS];
+#pragma unroll
+        for (int c = 0; c < VS / 4; c++) {
+            const real4 v = reinterpret_cast<const real4*>(win + blk * VS)[c];
+            w[4 * c] = v.x; w[4 * c + 1] = v.y; w[4 * c + 2] = v.z; w[4 * c + 3] = v.w;
+        }
+#pragma unroll
+        for (int c = 0; c < NXT / 2; c++) {
+            const f32x2 wv = {w[2 * c], w[2 * c + 1]};
+#pragma unroll
+            for (int u = 0; u < RPT; u++) a2[u] = __builtin_elementwise_fma(f32x2{rows[u][blk * NXT + 2 * c], rows[u][blk * NXT + 2 * c + 1]}, wv, a2[u]);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < RPT; u++) acc[u] = a2[u].x + a2[u].y;
+}
+
 // Same dot products with the rows' RIGHT block (the last nx entries) parked in LDS as real4 [chunk][thread] (conflict-free): the
 // iteration loop then needs nx x RPT fewer registers.  Only for nx % 4 == 0.
 template<int NXT, int RPT> GATO_DEV void rows_dot_parked(const float (*rows)[3 * NXT], const float* __restrict__ win, const real4* park, int T,
@@ -1711,10 +1740,16 @@ __global__ __launch_bounds__(MAXT) void pcgc_kernel(Buffers bf, int N, int B, ui
     extern __shared__ __attribute__((aligned(16))) float lds[];
     if (bf.ctrl->done) return;
     const int b = bf.order[blockIdx.x];   // hardest-first where the launch runs in rounds (solver.hip: pcg_rounds), else the identity
-    const int nrows = N * NX, vecp = (N + 2) * NX;
+    // block stride of the two LDS vectors: nx, or the next multiple of 4 where nx % 4 != 0 (16-byte aligned windows, rows_dot_strided);
+    // GATO_PCG_VSTRIDE=0 at build time keeps the dense layout (the A/B switch of the measurement in DESIGN.md section 6)
+#ifndef GATO_PCG_VSTRIDE
+#define GATO_PCG_VSTRIDE 1
+#endif
+    constexpr int VS = (NX % 4 == 0 || !GATO_PCG_VSTRIDE || PAIR) ? NX : ((NX + 3) & ~3);
+    const int nrows = N * NX, vecp = (N + 2) * NX, vecl = (N + 2) * VS;
     float* va = lds;
-    float* vb = lds + vecp;
-    float* partA = vb + ((vecp + 3) & ~3);
+    float* vb = lds + vecl;
+    float* partA = vb + ((vecl + 3) & ~3);
     float* partB = partA + 16;
     if (threadIdx.x < 32) partA[threadIdx.x] = 0.f;
     const float abs_tol = 1e-6f;
@@ -1997,24 +2032,33 @@ __global__ __launch_bounds__(MAXT) void pcgc_kernel(Buffers bf, int N, int B, ui
                 if (owner) store_vec<RPT, RPT>(lam + NX + rr, xv);
             }
         } else {
-        const float* wa = va + kb * NX;
-        const float* wb = vb + kb * NX;
-        float* oa = va + NX + rr;
-        float* ob = vb + NX + rr;
-        for (int i = threadIdx.x; i < NX; i += blockDim.x) {
+        const float* wa = va + kb * VS;
+        const float* wb = vb + kb * VS;
+        float* oa = va + (kb + 1) * VS + (rr - kb * NX);
+        float* ob = vb + (kb + 1) * VS + (rr - kb * NX);
+        for (int i = threadIdx.x; i < VS; i += blockDim.x) {
             va[i] = 0.f; vb[i] = 0.f;
-            va[vecp - NX + i] = 0.f; vb[vecp - NX + i] = 0.f;
+            va[vecl - VS + i] = 0.f; vb[vecl - VS + i] = 0.f;
         }
+        // S x, S p and P^-1 r of the thread's rows against the window [block kb-1 | kb | kb+1] of an LDS vector
+        auto sdot = [&](const float* win, float* out) {
+            if constexpr (VS != NX) rows_dot_strided<NX, RPT, VS>(Srow, win, out);
+            else rows_dot<NX, RPT>(Srow, win, out);
+        };
+        auto pdot = [&](const float* win, float* out) {
+            if constexpr (PARK) rows_dot_parked<NX, RPT>(Prow, win, park, blockDim.x, out);
+            else if constexpr (VS != NX) rows_dot_strided<NX, RPT, VS>(Prow, win, out);
+            else rows_dot<NX, RPT>(Prow, win, out);
+        };
         if (have) store_vec<RPT, RPT>(oa, xv);
         __syncthreads();
         float acc[RPT];
-        rows_dot<NX, RPT>(Srow, wa, acc);  // r = gamma - S x
+        sdot(wa, acc);  // r = gamma - S x
 #pragma unroll
         for (int u = 0; u < RPT; u++) rv[u] = have ? gv[u] - acc[u] : 0.f;
         if (have) store_vec<RPT, RPT>(ob, rv);
         __syncthreads();
-        if constexpr (PARK) rows_dot_parked<NX, RPT>(Prow, wb, park, blockDim.x, acc);
-        else rows_dot<NX, RPT>(Prow, wb, acc);  // z = p = P^-1 r
+        pdot(wb, acc);  // z = p = P^-1 r
         float loc = 0.f;
 #pragma unroll
         for (int u = 0; u < RPT; u++) {
@@ -2029,7 +2073,7 @@ __global__ __launch_bounds__(MAXT) void pcgc_kernel(Buffers bf, int N, int B, ui
                 iters++;
                 if (have) store_vec<RPT, RPT>(oa, pv);
                 __syncthreads();
-                rows_dot<NX, RPT>(Srow, wa, acc);  // A p
+                sdot(wa, acc);  // A p
                 loc = 0.f;
 #pragma unroll
                 for (int u = 0; u < RPT; u++) {
@@ -2045,8 +2089,7 @@ __global__ __launch_bounds__(MAXT) void pcgc_kernel(Buffers bf, int N, int B, ui
                 }
                 if (have) store_vec<RPT, RPT>(ob, rv);
                 __syncthreads();
-                if constexpr (PARK) rows_dot_parked<NX, RPT>(Prow, wb, park, blockDim.x, acc);
-                else rows_dot<NX, RPT>(Prow, wb, acc);  // z = P^-1 r
+                pdot(wb, acc);  // z = P^-1 r
                 loc = 0.f;
 #pragma unroll
                 for (int u = 0; u < RPT; u++) {

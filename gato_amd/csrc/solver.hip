@@ -350,7 +350,8 @@ template<int NX, int RPT, int FORCE_WPS> struct PcgcShape {
     static constexpr int MAXT = WPS * 256;          // threads per block that still leave REGS registers per lane
     static int threads(int rows) { return (((rows + RPT - 1) / RPT + 63) / 64) * 64; }
 };
-static size_t pcg_vec_lds(const GatoSolver* s) { return (size_t)(2 * s->vecp + 36) * sizeof(float); }
+// the two LDS vectors of the register-resident kernels keep their blocks at a stride of nx rounded up to a multiple of 4 (pcgc_kernel: VS)
+static size_t pcg_vec_lds(const GatoSolver* s) { return (size_t)(2 * (s->N + 2) * ((s->nx + 3) & ~3) + 36) * sizeof(float); }
 static size_t pcg_fold_lds(const GatoSolver* s) { return (size_t)2 * s->N * s->nx * s->nx * sizeof(float); }
 
 // Dynamic LDS beyond the 64 KB default has to be asked for, per function and device; the status is checked (a refused request
@@ -434,6 +435,7 @@ template<class M> static int plan_pcg(GatoSolver* s)
     if ((v == 100 || v == 2) && pcgc_fits<M, 3>(s)) choice = 2;
     else if ((v == 100 || v == 3) && pcgc_fits<M, 2>(s)) choice = 3;
     else if ((v == 100 || v == 1) && pcgc_fits<M, 6>(s)) choice = 1;
+    if (v == 4 && pcgc_fits<M, 1, 4>(s)) choice = 4;   // one row per thread at four wavefronts per SIMD (measured at C5; never the default)
     // symmetric half storage: asked for (7), or the default where no full-storage kernel holds the system (iiwa14 N = 128)
     // ... and ahead of the 6-rows-per-thread form, whose 432 matrix registers per lane live in AGPRs (indy7 N = 128: 296 vs 341 us per
     // one-iteration solve at B = 1, 1.49 vs 1.96 ms at B = 1024)
@@ -447,6 +449,7 @@ template<class M> static int plan_pcg(GatoSolver* s)
             case 2: fold = pcgc_grant_fold<M, 3>(s); break;
             case 3: fold = pcgc_grant_fold<M, 2>(s); break;
             case 1: fold = pcgc_grant_fold<M, 6>(s); break;
+            case 4: fold = pcgc_grant_fold<M, 1, 4>(s); break;
             case 7: break;   // granted with the kernel (pcgs_grant)
         }
     }
@@ -483,7 +486,7 @@ template<class M> static int plan_pcg(GatoSolver* s)
     // long one.  Measured: C5 shard 4.72 -> 4.18 ms per solve, C2 1.81 -> 1.76 ms.  Results do not depend on the order.
     {
         const char* oe = getenv("GATO_PCG_ORDER");
-        const bool can = step_fused(s) && (choice == 1 || choice == 2 || choice == 3);
+        const bool can = step_fused(s) && (choice == 1 || choice == 2 || choice == 3 || choice == 4);
         s->pcg_rounds = can && (oe ? atoi(oe) != 0 : s->B > s->cus) ? 2 : 1;
     }
     return GATO_OK;
@@ -560,6 +563,7 @@ template<class M> static void launch_pcg(GatoSolver* s, hipStream_t st, int sqp_
         case 2: launch_pcgc<M, 3>(s, st, sqp_iter, write_p); return;
         case 3: launch_pcgc<M, 2>(s, st, sqp_iter, write_p); return;
         case 1: launch_pcgc<M, 6>(s, st, sqp_iter, write_p); return;
+        case 4: launch_pcgc<M, 1, 4>(s, st, sqp_iter, write_p); return;
         case 7: launch_pcgs<M>(s, st, sqp_iter, s->pcg_fold != 0); return;
         default: break;
     }

@@ -60,3 +60,5 @@ def test_json_line(extra, workload):
         assert k in cb, k
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == d["unit"]
     assert d.get("solution_ok") is True
+    ps = d["parity_sample"]
+    assert ps["rows"] >= 8 and ps["rows_on_the_oracles_step_or_a_tie"] >= ps["rows_required"] and ps["initial_merit_rel_err"] < 1e-5
