@@ -71,6 +71,9 @@ struct GatoSolver {
     int pcg_choice, pcg_fold, pcg_fused, pcg_pair;
     int cus;   // compute units of the solver's device
     int pcg_rounds;   // > 1: the PCG workgroups are scheduled hardest-first (Buffers::order), see plan_pcg
+    int persist;      // the whole SQP loop of a solve as ONE launch of sqp_pair_kernel (plan_pcg: indy7 N = 32, every pair resident; GATO_PERSIST = 0 / 1)
+    unsigned long long* d_pair_trace = nullptr;   // GATO_PAIR_TRACE: per-workgroup wall-clock stamps of sqp_pair_kernel ([wgs][32])
+    int pair_slot = -1;   // this handle's slot of g_pair_tab: the constant-memory copy of `bf` that kernel reads (xu / x_s / ref travel as kernel arguments); upload_bf
     int32_t* d_order;
     int merit_in_step_forced;   // GATO_MERIT_IN_STEP = 0 / 1, else -1
     int linear_solver;  // 0: PCG (the reference's solver, pcg.cuh), 1: direct block-tridiagonal sweep (gato_set_linear_solver)
@@ -158,6 +161,19 @@ extern "C" int gato_dims(int plant, int N, int* nq, int* nx, int* nu, int* traj)
 
 static int plan_pcg_dispatch(GatoSolver* s);
 static int sync_last(GatoSolver* s);
+// The constant-memory copy of the buffer table (kernels.hpp: g_pair_tab) follows every change of a persistent pointer in it (creation, the
+// solved-count split of a sharded batch).  One slot per handle, PAIR_SLOTS per process; a handle that gets none keeps the launched loop.
+static bool g_slot_used[PAIR_SLOTS];
+static int upload_bf(GatoSolver* s)
+{
+    if (s->pair_slot < 0) {
+        for (int i = 0; i < PAIR_SLOTS && s->pair_slot < 0; i++)
+            if (!__atomic_test_and_set(&g_slot_used[i], __ATOMIC_ACQ_REL)) s->pair_slot = i;
+        if (s->pair_slot < 0) return GATO_OK;   // no slot: plan_pcg leaves `persist` off
+    }
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_pair_tab), &s->bf, sizeof(Buffers), (size_t)s->pair_slot * sizeof(Buffers), hipMemcpyHostToDevice));
+    return GATO_OK;
+}
 
 static int create_impl(GatoSolver* s, int plant, int N, int B, const GatoParams* params)
 {
@@ -205,7 +221,9 @@ static int create_impl(GatoSolver* s, int plant, int N, int B, const GatoParams*
         auto up = [](size_t n) { return (n + 63) & ~(size_t)63; };  // 256-byte granules, in 4-byte words
         const size_t o_dz = 0, o_pi = up((size_t)B * s->traj), o_cv = o_pi + up(B), o_ct = o_cv + up(B), o_ns = o_ct + up(sizeof(Ctrl) / 4);
         const size_t o_nsl = o_ns + up(s->max_iters_alloc);   // this rank's own solved counts (sharded batch)
-        s->zero_words = o_nsl + up(s->max_iters_alloc);
+        const size_t o_pd = o_nsl + up(s->max_iters_alloc);   // sqp_pair_kernel: workgroups past the PCG of iteration i
+        const size_t o_pf = o_pd + up(s->max_iters_alloc);    // sqp_pair_kernel: workgroups that have finished the solve
+        s->zero_words = o_pf + up(1);
         float* slab = nullptr;
         DA(slab, s->zero_words);
         s->zero_slab = slab;
@@ -216,6 +234,8 @@ static int create_impl(GatoSolver* s, int plant, int N, int B, const GatoParams*
         bf.num_solved = reinterpret_cast<uint32_t*>(slab + o_ns);
         bf.num_solved_w = bf.num_solved;   // one GPU: the count the exit rule reads is the one the PCG kernels add to
         s->d_ns_local = reinterpret_cast<uint32_t*>(slab + o_nsl);
+        bf.pcg_done = reinterpret_cast<uint32_t*>(slab + o_pd);
+        bf.pair_fin = reinterpret_cast<uint32_t*>(slab + o_pf);
     }
     DA(bf.merit, (size_t)B * NUM_ALPHAS); DA(bf.merit_cur, B); DA(bf.step, B); DA(s->d_order, B);
     DA(bf.st_pcg_iters, (size_t)s->max_iters_alloc * B); DA(bf.st_min_merit, (size_t)s->max_iters_alloc * B);
@@ -261,6 +281,8 @@ static int create_impl(GatoSolver* s, int plant, int N, int B, const GatoParams*
         HIPCHK(hipMemcpy(s->d_costw, w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice));
     }
     HIPCHK(hipDeviceSynchronize());
+    int rc_b = upload_bf(s);
+    if (rc_b != GATO_OK) return rc_b;
     return plan_pcg_dispatch(s);
 }
 
@@ -294,6 +316,7 @@ extern "C" int gato_destroy(GatoSolver* s)
     if (s->d_ee_out) (void)hipFree(s->d_ee_out);
     if (s->d_plant) (void)hipFree(s->d_plant);
     if (s->graph_exec) (void)hipGraphExecDestroy(s->graph_exec);
+    if (s->pair_slot >= 0) __atomic_clear(&g_slot_used[s->pair_slot], __ATOMIC_RELEASE);
     if (s->h_counts) (void)hipHostFree(s->h_counts);
     if (s->h_mpc_in) (void)hipHostFree(s->h_mpc_in);
     if (s->h_mpc_out) (void)hipHostFree(s->h_mpc_out);
@@ -488,6 +511,26 @@ template<class M> static int plan_pcg(GatoSolver* s)
         const char* oe = getenv("GATO_PCG_ORDER");
         const bool can = step_fused(s) && (choice == 1 || choice == 2 || choice == 3 || choice == 4);
         s->pcg_rounds = can && (oe ? atoi(oe) != 0 : s->B > s->cus) ? 2 : 1;
+    }
+    // The whole loop in one persistent launch (sqp_pair_kernel): two trajectories per 4-wavefront workgroup at 2 wavefronts per SIMD, every
+    // workgroup resident at once (a workgroup whose trajectories are all converged spins on the others' arrival).  Whether a given solve may
+    // use it (unsharded, PCG, solve_ratio >= 1, no per-stage profiling) is decided per solve: persist_ok.
+    s->persist = 0;
+    if constexpr (NX == 12) {
+        const char* pe = getenv("GATO_PERSIST");
+        const size_t lds = 2 * pcg_fused_lds<M>(s);
+        const long wgs = ((long)s->B + 1) / 2;
+        const bool can = s->pair_slot >= 0 && fused && s->N == 32 && step_fused(s) && wgs <= (long)s->cus * 2 && kkt_tasks<M>() == 4 &&
+                         grant_lds(reinterpret_cast<const void*>(&sqp_pair_kernel<M>), lds);
+        // OPT-IN (GATO_PERSIST=1): measured at C2 it is not faster than the launched loop (1.74 against 1.72 ms per solve; B = 512: 1.65 against
+        // 1.42 ms, where the launched loop runs the pair form): the median workgroup finishes after 1.38 ms, but the solve lasts as long as the
+        // workgroup that holds the hardest trajectory -- 1015 PCG iterations at ~1.0 us plus ten times (assembly + prologue + two steps) at the
+        // rates of a busy chip = 1.8 ms (wall-clock stamps per workgroup: tools/exp/pair_trace.py, profiles/r04_pair_trace.txt)
+        s->persist = can && pe && atoi(pe) != 0 ? 1 : 0;
+        if (s->persist && getenv("GATO_PAIR_TRACE") && !s->d_pair_trace) {
+            const int rc = dalloc(s, &s->d_pair_trace, (size_t)wgs * 32);
+            if (rc != GATO_OK) return rc;
+        }
     }
     return GATO_OK;
 }
@@ -770,6 +813,7 @@ static void set_sharded(GatoSolver* s, long global_batch)
     drop_graph(s);
     s->global_batch = global_batch;
     s->bf.num_solved_w = global_batch > 0 ? s->d_ns_local : s->bf.num_solved;
+    (void)upload_bf(s);   // callers have synchronised the solver's stream (sync_last)
 }
 
 extern "C" int gato_comm_unique_id(char* out128)
@@ -914,6 +958,27 @@ template<class M> static int enqueue_solve(GatoSolver* s, float dt, hipStream_t 
     return GATO_OK;
 }
 
+// ---- the persistent form: one memset + ONE launch per solve (kernels.hpp: sqp_pair_kernel) -------------------------------------------------
+static bool persist_ok(const GatoSolver* s, uint32_t iters)
+{
+    // the exit rule's fast path needs "the rule fires only when every trajectory is converged": threshold >= batch
+    return s->persist && iters > 0 && s->linear_solver == 0 && !s->profiling && s->global_batch == 0 && exit_threshold_exact(s) >= (float)s->B;
+}
+template<class M> static int enqueue_persistent(GatoSolver* s, float dt, hipStream_t st, uint32_t iters)
+{
+    constexpr int NX = 2 * M::NQ;
+    if constexpr (NX == 12) {
+        HIPCHK(hipMemsetAsync(s->zero_slab, 0, s->zero_words * sizeof(float), st));   // dz, PCG counts, convergence flags, loop control, counters
+        const int wgs = (s->B + 1) / 2;
+        hipLaunchKernelGGL((sqp_pair_kernel<M>), dim3(wgs), dim3(256), 2 * pcg_fused_lds<M>(s), st, s->pair_slot, s->bf.xu, s->bf.x_s, s->bf.ref, s->N, s->B, dt, iters,
+                           s->p.max_pcg_iters, exit_threshold_exact(s), s->adapt_rho, (const float*)s->d_drho_init, s->d_merit_init0, s->d_pair_trace);
+        HIPCHK(hipGetLastError());
+        return GATO_OK;
+    } else {
+        return fail(GATO_ERR_INVALID, "the persistent loop exists for nx = 12");
+    }
+}
+
 // async_only: the caller cannot take a host synchronisation inside the solve (stream capture): a sharded solve then shares the count per iteration
 template<class M> static int solve_impl(GatoSolver* s, float* d_xu, float dt, const float* d_xs, const float* d_ref, hipStream_t st, bool async_only = false)
 {
@@ -924,6 +989,7 @@ template<class M> static int solve_impl(GatoSolver* s, float* d_xu, float dt, co
     s->last_stream_valid = true;
     const uint32_t iters = s->p.max_sqp_iters <= s->max_iters_alloc ? s->p.max_sqp_iters : s->max_iters_alloc;
     const bool sharded = s->global_batch > 0;
+    if (!sharded && persist_ok(s, iters)) return enqueue_persistent<M>(s, dt, st, iters);
     if (!sharded) return enqueue_solve<M>(s, dt, st, iters, false);
     if (!s->deferred_count || async_only || iters == 0) return enqueue_solve<M>(s, dt, st, iters, true);
     // ---- deferred: the solved count is the ONLY coupling between the shards (bsqp.cuh:165) and on every workload where trajectories do not
@@ -1586,11 +1652,24 @@ extern "C" int gato_debug_read(GatoSolver* s, const char* name, float* out, uint
     GUARD(s);
     uint64_t l = 0;
     float* p = find_buf(s, name, &l);
+    if (!p && !strcmp(name, "pair_trace")) {   // microseconds since the earliest start stamp (wall_clock64 ticks at 100 MHz), 0 where nothing was stamped
+        const size_t n = s->d_pair_trace ? (size_t)((s->B + 1) / 2) * 32 : 0;
+        if (len) *len = n;
+        if (!out || !n) return GATO_OK;
+        std::vector<unsigned long long> t(n);
+        HIPCHK(hipDeviceSynchronize());
+        HIPCHK(hipMemcpy(t.data(), s->d_pair_trace, n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        unsigned long long t0 = ~0ull;
+        for (size_t i = 0; i < n; i += 32) if (t[i] && t[i] < t0) t0 = t[i];
+        for (size_t i = 0; i < n && i < count; i++) out[i] = t[i] ? (float)((double)(t[i] - t0) / 100.0) : (float)0;
+        return GATO_OK;
+    }
     if (!p) {
-        if (!strcmp(name, "pcg_iters") || !strcmp(name, "converged")) {  // integer buffers, returned as floats
+        if (!strcmp(name, "pcg_iters") || !strcmp(name, "converged") || !strcmp(name, "order")) {  // integer buffers, returned as floats
             std::vector<int32_t> t(s->B);
             HIPCHK(hipDeviceSynchronize());
-            HIPCHK(hipMemcpy(t.data(), !strcmp(name, "pcg_iters") ? (void*)s->bf.pcg_iters : (void*)s->bf.converged, s->B * sizeof(int32_t), hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(t.data(), !strcmp(name, "pcg_iters") ? (void*)s->bf.pcg_iters : (!strcmp(name, "order") ? (void*)s->d_order : (void*)s->bf.converged), s->B * sizeof(int32_t),
+                             hipMemcpyDeviceToHost));
             if (len) *len = s->B;
             if (out) for (uint64_t i = 0; i < count && i < (uint64_t)s->B; i++) out[i] = (float)t[i];
             return GATO_OK;
