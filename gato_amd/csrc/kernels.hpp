@@ -38,6 +38,15 @@ namespace gato {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));   // a pair of reals: one v_pk_fma_f32 per fma in the fp32 build
 
+// The LDS vectors of the register-resident PCG kernels keep their blocks at a stride of nx rounded up to a multiple of 4 (16-byte aligned
+// windows for nx = 14); GATO_PCG_VSTRIDE=0 at build time keeps the dense layout (the A/B switch of the measurement in DESIGN.md section 6)
+#ifndef GATO_PCG_VSTRIDE
+#define GATO_PCG_VSTRIDE 1
+#endif
+#ifndef GATO_PCGS_VSTRIDE
+#define GATO_PCGS_VSTRIDE 0   // the same layout in pcgs_kernel (symmetric half storage): MEASURED SLOWER, off -- the two floats of padding a window's last
+                              // ds_read_b128 brings along cost that kernel 20 more bytes of scratch inside its loop (256 registers, 36 -> 56 bytes): C3 577 vs 397 us per launch
+#endif
 constexpr int NUM_ALPHAS = 8;        // settings.h:16
 constexpr float RHO_FACTOR = 1.2f;   // settings.h:20
 constexpr float RHO_MIN = 1e-8f;     // settings.h:21
@@ -1766,10 +1775,6 @@ GATO_DEV void pcgc_body(const Buffers& bf, int N, int B, int b, unsigned tx, uns
     constexpr int LA2 = (NX % 4 == 0) ? 4 : 2;  // alignment (floats) of an nx-float row in the LDS buffers
     static_assert(NX % RPT == 0, "rows of one thread must share a block row");
     // block stride of the two LDS vectors: nx, or the next multiple of 4 where nx % 4 != 0 (16-byte aligned windows, rows_dot_strided);
-    // GATO_PCG_VSTRIDE=0 at build time keeps the dense layout (the A/B switch of the measurement in DESIGN.md section 6)
-#ifndef GATO_PCG_VSTRIDE
-#define GATO_PCG_VSTRIDE 1
-#endif
     constexpr int VS = (NX % 4 == 0 || !GATO_PCG_VSTRIDE || PAIR) ? NX : ((NX + 3) & ~3);
     const int nrows = N * NX, vecp = (N + 2) * NX, vecl = (N + 2) * VS;
     float* va = lds;
@@ -2258,10 +2263,13 @@ __global__ __launch_bounds__(MAXT, 2) void pcgs_kernel(Buffers bf, int N, int B,
     extern __shared__ __attribute__((aligned(16))) float lds[];
     if (bf.ctrl->done) return;
     const int b = blockIdx.x, t = threadIdx.x, T = blockDim.x;  // T = 4 N, a multiple of 64
-    const int vecp = (N + 2) * NX;
+    // the two LDS vectors keep their blocks at a stride of VS floats = nx rounded up to a multiple of 4 (pcgc_body: the same layout): a thread's
+    // window is one 16-byte aligned block, four ds_read_b128 instead of seven 8-byte reads
+    constexpr int VS = (NX % 4 == 0 || !GATO_PCGS_VSTRIDE) ? NX : ((NX + 3) & ~3);
+    const int vecp = (N + 2) * NX, vecl = (N + 2) * VS;
     float* va = lds;
-    float* vb = va + vecp;
-    float* partA = vb + ((vecp + 3) & ~3);
+    float* vb = va + vecl;
+    float* partA = vb + ((vecl + 3) & ~3);
     float* partB = partA + 16;
     float* rowbuf = partB + 16;                // [N nx]: the left-block part of every row's product
     float* tbuf = rowbuf + N * NX;             // [N + 1][2][nx]: transposed partials of block k, by row half; block N stays zero
@@ -2369,14 +2377,14 @@ __global__ __launch_bounds__(MAXT, 2) void pcgs_kernel(Buffers bf, int N, int B,
             xv[i] = mainrole ? lam[NX + r0 + i] : 0.f;
             gv[i] = mainrole ? gam[NX + r0 + i] : 0.f;
         }
-        for (int i = t; i < NX; i += T) {
+        for (int i = t; i < VS; i += T) {
             va[i] = 0.f; vb[i] = 0.f;
-            va[vecp - NX + i] = 0.f; vb[vecp - NX + i] = 0.f;
+            va[vecl - VS + i] = 0.f; vb[vecl - VS + i] = 0.f;
         }
         for (int i = t; i < 2 * NX; i += T) tbuf[N * 2 * NX + i] = 0.f;
-        const float* wina = va + (k + (mainrole ? 1 : 0)) * NX;   // the role's window: block k-1 (left) or k (main) of the padded vector
-        const float* winb = vb + (k + (mainrole ? 1 : 0)) * NX;
-        const int own = NX + r0;                                   // the thread's rows in the padded vectors
+        const float* wina = va + (k + (mainrole ? 1 : 0)) * VS;   // the role's window: block k-1 (left) or k (main) of the padded vector
+        const float* winb = vb + (k + (mainrole ? 1 : 0)) * VS;
+        const int own = (k + 1) * VS + h * HR;                     // the thread's rows in the padded vectors
 
         // out[i] = row r0 + i of Mx v for the main role; `vec` is the LDS copy of v (published by the caller's barrier); ISP: Mx = P^-1.
         // The roles are whole wavefronts, so each takes ONE branch per product and runs straight-line code inside it.
@@ -2386,8 +2394,9 @@ __global__ __launch_bounds__(MAXT, 2) void pcgs_kernel(Buffers bf, int N, int B,
         // before the barrier and summed after it (4 barriers per PCG iteration instead of 6).  `vown`: the main role's rows of v.
         auto matvec = [&](const float* vec, const float* win, auto isp, float* out, const float* vown, float* part) -> float {
             constexpr bool ISP = decltype(isp)::value;
-            float acc[HR], w[NX];
-            load_vec<NX, 2>(w, win);
+            float acc[HR], w[VS];
+            if constexpr (VS != NX) load_vec<VS, 4>(w, win);   // (the block's two padding floats ride along, unused)
+            else load_vec<NX, 2>(w, win);
             float dotc = 0.f;
             if (!mainrole) {
                 float tp[NX], vo[HR];

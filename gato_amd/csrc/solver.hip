@@ -422,7 +422,8 @@ template<class M> static size_t pcg_fused_lds(const GatoSolver* s)
 static size_t pcgs_lds(const GatoSolver* s)
 {
     const size_t T = 4 * (size_t)s->N, nx = s->nx;
-    return ((size_t)2 * s->vecp + 36 + (size_t)s->N * nx + (size_t)(s->N + 1) * 2 * nx) * sizeof(float) + (4 * nx / 4) * T * sizeof(real4);
+    const size_t vecl = (size_t)(s->N + 2) * ((nx + 3) & ~(size_t)3);   // the LDS vectors' block stride (pcgs_kernel: VS)
+    return ((size_t)2 * vecl + 36 + (size_t)s->N * nx + (size_t)(s->N + 1) * 2 * nx) * sizeof(float) + (4 * nx / 4) * T * sizeof(real4);
 }
 template<class M> static bool pcgs_grant(const GatoSolver* s)
 {
