@@ -5,7 +5,7 @@ tolerance"):
   stage outputs from identical inputs      rel <= 1e-5  (dynamics, cost blocks, dz, merit)      [measured ~1e-6]
   Schur blocks / Gauss-Jordan inverses     rel <= 1e-4  (no pivoting amplifies rounding)        [measured ~3e-6]
   lambda from PCG                          rel <= 1e-3  (stops at a residual tolerance), iteration counts within +-1
-  one SQP iteration, PCG at its floor      every trajectory: XU rel <= 1e-4 (iiwa14 3e-4), identical steps
+  one SQP iteration, PCG at its floor      every trajectory: XU rel <= 1e-4 (iiwa14 2e-4), identical steps
   three SQP iterations, PCG at its floor   every trajectory: identical steps, error against the FLOAT64 build of the oracle no larger than
                                            max(2e-4, 4 x the fp32 oracle's own error against it) -- fp32 itself is 2e-4 (1 iteration) to
                                            2e-3 (3 iterations) away from float64 on this problem (tools/sensitivity.py), so
@@ -175,9 +175,11 @@ def test_iterate_parity_tight_pcg(plant, N, B):
     np.testing.assert_array_equal(rg["ls_step_size"], ro["ls_step_size"])
     e = traj_err(rg["XU"], ro["XU"])
     _report("tight_1it", plant=plant, N=N, xu=e.max(), merit=relscale(rg["final_merit"], ro["final_merit"]))
-    # indy7 meets the north-star's 1e-4; iiwa14's Schur system is worse conditioned (1.1e-4 between two fp32 summation orders; the fp32
-    # oracle itself is 2e-4 .. 3e-4 from its float64 build here)
-    assert e.max() < (1e-4 if plant == "indy7" else 3e-4), e
+    # indy7 meets the north-star's 1e-4; iiwa14: 1.4e-4 .. 1.6e-4 measured on these rows, bound 2e-4 (round 4, tightened from 3e-4).  No stage
+    # carries the difference (tools/stage_errors.py): every tensor up to gamma is at fp32 rounding on both paths, the
+    # error enters with lambda -- cond(S) ~ 1e9 times that rounding, plus PCG's own fp32 floor -- and the fp32 oracle itself is 2e-4 .. 3e-4
+    # from its float64 build here.  Whole batches: tests/test_full_size_oracle_gpu.py (max / 99th percentile / median).
+    assert e.max() < (1e-4 if plant == "indy7" else 2e-4), e
     # the merit amplifies iterate differences (mu * |defect|_1 goes through M^-1 ~ 1e3 on the last joints): 1e-4 in XU is ~1e-2 here
     assert relscale(rg["final_merit"], ro["final_merit"]) < 2e-2
     assert relscale(rg["ls_min_merit"], ro["ls_min_merit"]) < 2e-2
