@@ -184,6 +184,18 @@ def main():
     from gato_amd.bsqp.config import DEFAULT_SOLVER_PARAMS
     from gato_amd.bsqp.workloads import fig8_problem, hparam_problem
     plant, N, B = a.plant, a.knots, a.batch
+    # the CPU baseline runs the oracle compiled for THIS box's host (-O3 -march=native); the committed .so is x86-64-v3
+    oracle_build = "x86-64-v3 (committed build)"
+    if rank == 0 and not a.no_cpu_baseline and world == 1:
+        try:
+            import tempfile
+            from oracle import oracle as _orc
+            nat = _orc.build_native(tempfile.mkdtemp(prefix="gato_oracle_"))
+            if nat:
+                _orc.use_library(nat)
+                oracle_build = "-O3 -march=native, built on this host"
+        except Exception:   # noqa: BLE001
+            pass
     if a.workload == "hparam":
         # BASELINE config C5: rank g = shard g of the sweep (cost tuple g, per-trajectory rho, dt 0.05, mu 1, pcg_tol 1e-3)
         def make_problem(n, shard=rank):
@@ -428,6 +440,7 @@ def main():
     if not a.no_cpu_baseline and world == 1:
         line["cpu_baseline"] = cpu_baseline(plant, N, params, dt, a.cpu_sample, make_problem)
         line["cpu_baseline"]["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
+        line["cpu_baseline"]["build"] = oracle_build
     print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

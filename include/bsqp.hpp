@@ -85,6 +85,17 @@ struct SQPStats {  // gato/types.cuh:46-59
     std::vector<LineSearchStats<T, BatchSize>> line_search_stats;
 };
 
+// gato/types.cuh:63-81: pointer bundles the reference's class keeps for its own kernels.  No caller of the path touches them (the device
+// buffers are the solver's, behind the C ABI, in a COMPACT layout: DESIGN.md section 2); declared so that code naming the types compiles.
+template<typename T, uint32_t BatchSize>
+struct KKTSystem {
+    T *d_Q_batch, *d_R_batch, *d_q_batch, *d_r_batch, *d_A_batch, *d_B_batch, *d_c_batch;
+};
+template<typename T, uint32_t BatchSize>
+struct SchurSystem {
+    T *d_S_batch, *d_P_inv_batch, *d_gamma_batch;
+};
+
 template<typename T, uint32_t BatchSize>
 class BSQP {
     static_assert(std::is_same<T, gato_real>::value, "T must be the library's real type: float with libgato_hip.so, double with -DGATO_DOUBLE and libgato_hip_f64.so");

@@ -11,6 +11,25 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libgato_oracle.so")
+
+
+def build_native(out_dir):
+    """The fp32 oracle compiled for THIS host (-march=native, BASELINE.md section 3's CPU baseline flags) into out_dir; the committed
+    Makefile target is x86-64-v3 because that .so travels from the authoring container.  Returns the path, or None without a compiler."""
+    out = os.path.join(out_dir, "libgato_oracle_native.so")
+    try:
+        subprocess.check_call(["gcc", "-O3", "-march=native", "-fopenmp", "-fPIC", "-std=c99", "-ffp-contract=fast", "-shared", "-o", out,
+                               os.path.join(HERE, "gato_oracle.c"), "-lm"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        return out
+    except Exception:   # noqa: BLE001
+        return None
+
+
+def use_library(path):
+    """fp32 oracle from another build of the same source (build_native); must be called before the first solver is created"""
+    global LIB_PATH
+    assert False not in _libs, "the fp32 oracle library is already loaded"
+    LIB_PATH = path
 PLANTS = {"indy7": 0, "iiwa14": 1}
 NQ = {"indy7": 6, "iiwa14": 7}
 
