@@ -526,7 +526,7 @@ template<class M> static int plan_pcg(GatoSolver* s)
         // OPT-IN (GATO_PERSIST=1): measured at C2 it is not faster than the launched loop (1.74 against 1.72 ms per solve; B = 512: 1.65 against
         // 1.42 ms, where the launched loop runs the pair form): the median workgroup finishes after 1.38 ms, but the solve lasts as long as the
         // workgroup that holds the hardest trajectory -- 1015 PCG iterations at ~1.0 us plus ten times (assembly + prologue + two steps) at the
-        // rates of a busy chip = 1.8 ms (wall-clock stamps per workgroup: tools/exp/pair_trace.py, profiles/r04_pair_trace.txt)
+        // rates of a busy chip = 1.8 ms (wall-clock stamps per workgroup: tools/pair_trace.py, profiles/r04_pair_trace.txt)
         s->persist = can && pe && atoi(pe) != 0 ? 1 : 0;
         if (s->persist && getenv("GATO_PAIR_TRACE") && !s->d_pair_trace) {
             const int rc = dalloc(s, &s->d_pair_trace, (size_t)wgs * 32);
