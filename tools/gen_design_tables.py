@@ -58,7 +58,10 @@ def heatmap_block():
     """the reference's MPC solve-time heat-map next to this library's (profiles/r03_mpc_heatmap_*.json, tools/mpc_heatmap.py)"""
     cells, pub = {}, {}
     for f in ("short_pcg", "long_pcg", "long_direct"):
-        for c in json.load(open(os.path.join(ROOT, "profiles", "r03_mpc_heatmap_%s.json" % f))):
+        path = os.path.join(ROOT, "profiles", "r04_mpc_heatmap_%s.json" % f)   # the latest round that measured it
+        if not os.path.exists(path):
+            path = os.path.join(ROOT, "profiles", "r03_mpc_heatmap_%s.json" % f)
+        for c in json.load(open(path)):
             cells[(c["knots"], c["linear_solver"], c["batch"])] = c
             if c.get("published_ms") is not None:
                 pub[(c["knots"], c["batch"])] = c["published_ms"]
