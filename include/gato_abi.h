@@ -121,7 +121,7 @@ int gato_set_rho_adaptation(GatoSolver* s, int enabled);
  * fp32 rounding; pcg_iters reports 1 and no trajectory is ever flagged converged by the "0 PCG iterations" rule). */
 /* Replay the launch sequence of gato_solve (host-buffer form) as a hipGraph captured on first use (re-captured when dt, the iteration
  * count or a mode switch changes).  Off by default: measured on MI355X the kernels of a solve already run back to back, so the replay
- * changes the solve time by less than the run-to-run noise (DESIGN.md 6.4); results are bit-identical either way. */
+ * changes the solve time by less than the run-to-run noise (DESIGN.md section 6, item 5); results are bit-identical either way. */
 int gato_set_graph_mode(GatoSolver* s, int enabled);
 #define GATO_LINSOLVE_PCG 0
 #define GATO_LINSOLVE_DIRECT 1
