@@ -43,6 +43,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));   // a pair of reals: o
 #ifndef GATO_PCG_VSTRIDE
 #define GATO_PCG_VSTRIDE 1
 #endif
+#ifndef GATO_SCHUR1_STAGE
+#define GATO_SCHUR1_STAGE 1
+#endif
 #ifndef GATO_PCGS_VSTRIDE
 #define GATO_PCGS_VSTRIDE 0   // the same layout in pcgs_kernel (symmetric half storage): MEASURED SLOWER, off -- the two floats of padding a window's last
                               // ds_read_b128 brings along cost that kernel 20 more bytes of scratch inside its loop (256 registers, 36 -> 56 bytes): C3 577 vs 397 us per launch
@@ -1091,9 +1094,15 @@ __global__ __launch_bounds__(256) void schur1_kernel(Buffers bf, int N, int B, f
     }
     const int grp = threadIdx.x >> 4;
     __syncthreads();
-    if (!live) return;
-    const bool act = l < NX;
-    const int y = act ? l : 0;         // the 16 - nx spare lanes shadow row 0 and store nothing
+    // rows of nx = 14 floats are 56-byte pieces: with GATO_SCHUR1_STAGE the three blocks a knot writes go through the wavefront's own part of
+    // sAB (free once the theta columns are formed) and leave as whole 784-byte blocks in 16-byte stores.  Every lane then stays to the end
+    // (the copy-out is by wavefront); dead groups compute on whatever LDS holds and store nothing.
+    constexpr bool STAGE = GATO_SCHUR1_STAGE && (NX % 4 != 0) && (BLK % 4 == 0) && (NX % 2 == 0);
+    if constexpr (!STAGE) {
+        if (!live) return;
+    }
+    const bool act = live && l < NX;
+    const int y = l < NX ? l : 0;      // the 16 - nx spare lanes shadow row 0 and store nothing
     const bool upper = y < NQ;         // row in the q half
     const int rm = upper ? y : y - NQ;
     const float h2 = half_dt_sq(dt);
@@ -1171,6 +1180,9 @@ __global__ __launch_bounds__(256) void schur1_kernel(Buffers bf, int N, int B, f
             else t = (x - NQ == rm) ? td : 0.f;
             t += sacc;
             t += s2;
+            // the column is finished HERE: left to itself the compiler sinks the fourteen sums to the LDS stores below and keeps all 336 loaded
+            // A/B entries alive until then (256 VGPR + 132 AGPR instead of 98)
+            if constexpr (STAGE) asm volatile("" : "+v"(t));
             th[x] = t;
         }
     }
@@ -1193,14 +1205,43 @@ __global__ __launch_bounds__(256) void schur1_kernel(Buffers bf, int N, int B, f
         gg = -1.0f * g1;
     }
     float* S = bf.S + (size_t)b * N * BROW;
+    // staged copy-out: the wavefront's four knots are consecutive block rows (flat index b N + k + 1)
+    float* wst = sAB + (grp & ~3) * ABG;
+    const unsigned long long livem = __ballot(live);
+    auto put_row = [&](const float* rowv, float sgn) {
+        if (l < NX) {
+            float* d = wst + (grp & 3) * BLK + y * NX;
+#pragma unroll
+            for (int c = 0; c < NX; c += 2) *reinterpret_cast<real2*>(d + c) = make_real2(sgn * rowv[c], sgn * rowv[c + 1]);
+        }
+    };
+    auto copy_out = [&](float* field, int bt) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const long row1 = (long)blockIdx.x * 16 + (grp & ~3) + 1;
+        for (int i = threadIdx.x & 63; i < BLK; i += 64) {       // 4 blocks x BLK/4 vectors
+            const int gq = i / (BLK / 4), j = i - gq * (BLK / 4);
+            if ((livem >> (gq * 16)) & 1)
+                reinterpret_cast<real4*>(field + (size_t)(row1 + gq) * BROW + bt * BLK)[j] = reinterpret_cast<const real4*>(wst + gq * BLK)[j];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    };
+    if constexpr (STAGE) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the group's reads of its A/B rows are done
+        put_row(phi, 1.0f);
+        copy_out(bf.S, 0);
+        put_row(th, -1.0f);
+        copy_out(bf.S, 1);
+    }
     if (act) {
         float* Sk = S + (size_t)k * BROW;
         float* Sk1 = S + (size_t)(k + 1) * BROW;
-        float row[NX];
+        if constexpr (!STAGE) {
+            float row[NX];
 #pragma unroll
-        for (int x = 0; x < NX; x++) row[x] = -th[x];
-        gstore_vec<NX>(Sk1 + (size_t)y * NX, phi);          // the group's 14 rows of a block: one contiguous run
-        gstore_vec<NX>(Sk1 + BLK + (size_t)y * NX, row);
+            for (int x = 0; x < NX; x++) row[x] = -th[x];
+            gstore_vec<NX>(Sk1 + (size_t)y * NX, phi);          // the group's 14 rows of a block: one contiguous run
+            gstore_vec<NX>(Sk1 + BLK + (size_t)y * NX, row);
+        }
         if (write_right) {
 #pragma unroll
             for (int x = 0; x < NX; x++) Sk[2 * BLK + (size_t)x * NX + y] = phi[x];  // right block of row k = phi^T
@@ -1209,7 +1250,7 @@ __global__ __launch_bounds__(256) void schur1_kernel(Buffers bf, int N, int B, f
     }
     // (theta_k + rho I_q)^-1 by Gauss-Jordan across the group (schur_linsys.cuh:150-164)
     {
-        const float rho = bf.rho[b];
+        const float rho = bf.rho[live ? b : 0];
 #pragma unroll
         for (int c = 0; c < NQ; c++) th[c] += (c == y) ? rho : 0.f;  // first nq diagonal entries (only rows y < nq have c == y there)
 #pragma unroll
@@ -1234,7 +1275,10 @@ __global__ __launch_bounds__(256) void schur1_kernel(Buffers bf, int N, int B, f
                 th[c] = owner ? piv : yv;
             }
         }
-        if (act) {
+        if constexpr (STAGE) {
+            put_row(th, -1.0f);
+            copy_out(bf.Pinv, 1);
+        } else if (act) {
             float* Pk1 = bf.Pinv + ((size_t)b * N + k + 1) * BROW;
             float row[NX];
 #pragma unroll
