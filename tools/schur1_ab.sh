@@ -3,11 +3,11 @@
 #   cd gato_amd/csrc && hipcc $(CXXFLAGS) -DGATO_SCHUR1_STAGE=0 -shared -o ../../tools/exp/libgato_nostage.so solver.hip -ldl
 # then: gpurun -- bash tools/schur1_ab.sh   (bit comparison of one solve per library, then alternating bench runs)
 cd $GRAFT_REPO_ROOT
-python tools/dump_solve.py gpurun_out/s1_stage.npz
-GATO_HIP_LIB=$PWD/tools/exp/libgato_nostage.so python tools/dump_solve.py gpurun_out/s1_nostage.npz
+python tools/dump_solve.py /tmp/s1_stage.npz
+GATO_HIP_LIB=$PWD/tools/exp/libgato_nostage.so python tools/dump_solve.py /tmp/s1_nostage.npz
 python - <<'PY'
 import numpy as np
-a=np.load("gpurun_out/s1_stage.npz"); b=np.load("gpurun_out/s1_nostage.npz")
+a=np.load("/tmp/s1_stage.npz"); b=np.load("/tmp/s1_nostage.npz")
 for k in a.files:
     same = a[k].tobytes()==b[k].tobytes()
     print(k, "SAME" if same else "DIFF", a[k].shape)
