@@ -43,6 +43,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));   // a pair of reals: o
 #ifndef GATO_PCG_VSTRIDE
 #define GATO_PCG_VSTRIDE 1
 #endif
+#ifndef GATO_PCG_VSKEW
+#define GATO_PCG_VSKEW 4   // floats added to a block stride that is a multiple of 16 (64 bytes): see pcg_vec_stride
+#endif
 #ifndef GATO_SCHUR1_STAGE
 #define GATO_SCHUR1_STAGE 1
 #endif
@@ -50,6 +53,16 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));   // a pair of reals: o
 #define GATO_PCGS_VSTRIDE 0   // the same layout in pcgs_kernel (symmetric half storage): MEASURED SLOWER, off -- the two floats of padding a window's last
                               // ds_read_b128 brings along cost that kernel 20 more bytes of scratch inside its loop (256 registers, 36 -> 56 bytes): C3 577 vs 397 us per launch
 #endif
+// Block stride (floats) of the LDS vectors of the register-resident PCG kernels.  nx % 4 == 0: dense.  Otherwise nx rounded up to whole 16-byte
+// chunks -- and, where that is a multiple of 16 floats (nx = 14 -> 16), GATO_PCG_VSKEW floats more: the lanes of a wavefront that own
+// consecutive block rows read the same chunk of consecutive blocks in ONE ds_read_b128, and at a 64-byte stride blocks k and k + 4 (k + 2 on 32
+// banks) start on the same bank: 41 % of C5's LDS cycles were bank conflicts at stride 16 (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE, 3.5 % at
+// the dense 14); at 20 the nine block rows of a wavefront start on nine different 4-bank slots.
+constexpr int pcg_vec_stride(int nx)
+{
+    const int lw = (nx + 3) & ~3;
+    return nx % 4 == 0 ? nx : (lw % 16 == 0 ? lw + GATO_PCG_VSKEW : lw);
+}
 constexpr int NUM_ALPHAS = 8;        // settings.h:16
 constexpr float RHO_FACTOR = 1.2f;   // settings.h:20
 constexpr float RHO_MIN = 1e-8f;     // settings.h:21
@@ -1651,14 +1664,15 @@ template<int NXT, int RPT, bool PACKED = true> GATO_DEV void rows_dot(const floa
 template<int NXT, int RPT, int VS> GATO_DEV void rows_dot_strided(const float (*rows)[3 * NXT], const float* __restrict__ win, float* acc)
 {
     static_assert(NXT % 2 == 0 && VS % 4 == 0 && VS >= NXT, "blocks of whole pairs at a 16-byte stride");
+    constexpr int LW = (NXT + 3) & ~3;   // floats fetched per block (whole 16-byte chunks; the stride may be larger: pcg_vec_stride)
     f32x2 a2[RPT];
 #pragma unroll
     for (int u = 0; u < RPT; u++) a2[u] = f32x2{0.f, 0.f};
 #pragma unroll
     for (int blk = 0; blk < 3; blk++) {
-        float w[VS];
+        float w[LW];
 #pragma unroll
-        for (int c = 0; c < VS / 4; c++) {
+        for (int c = 0; c < LW / 4; c++) {
             const real4 v = reinterpret_cast<const real4*>(win + blk * VS)[c];
             w[4 * c] = v.x; w[4 * c + 1] = v.y; w[4 * c + 2] = v.z; w[4 * c + 3] = v.w;
         }
@@ -1819,7 +1833,7 @@ GATO_DEV void pcgc_body(const Buffers& bf, int N, int B, int b, unsigned tx, uns
     constexpr int LA2 = (NX % 4 == 0) ? 4 : 2;  // alignment (floats) of an nx-float row in the LDS buffers
     static_assert(NX % RPT == 0, "rows of one thread must share a block row");
     // block stride of the two LDS vectors: nx, or the next multiple of 4 where nx % 4 != 0 (16-byte aligned windows, rows_dot_strided);
-    constexpr int VS = (NX % 4 == 0 || !GATO_PCG_VSTRIDE || PAIR) ? NX : ((NX + 3) & ~3);
+    constexpr int VS = (NX % 4 == 0 || !GATO_PCG_VSTRIDE || PAIR) ? NX : pcg_vec_stride(NX);
     const int nrows = N * NX, vecp = (N + 2) * NX, vecl = (N + 2) * VS;
     float* va = lds;
     float* vb = lds + vecl;

@@ -374,7 +374,7 @@ template<int NX, int RPT, int FORCE_WPS> struct PcgcShape {
     static int threads(int rows) { return (((rows + RPT - 1) / RPT + 63) / 64) * 64; }
 };
 // the two LDS vectors of the register-resident kernels keep their blocks at a stride of nx rounded up to a multiple of 4 (pcgc_kernel: VS)
-static size_t pcg_vec_lds(const GatoSolver* s) { return (size_t)(2 * (s->N + 2) * ((s->nx + 3) & ~3) + 36) * sizeof(float); }
+static size_t pcg_vec_lds(const GatoSolver* s) { return (size_t)(2 * (s->N + 2) * pcg_vec_stride(s->nx) + 36) * sizeof(float); }
 static size_t pcg_fold_lds(const GatoSolver* s) { return (size_t)2 * s->N * s->nx * s->nx * sizeof(float); }
 
 // Dynamic LDS beyond the 64 KB default has to be asked for, per function and device; the status is checked (a refused request
