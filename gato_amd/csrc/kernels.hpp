@@ -46,6 +46,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));   // a pair of reals: o
 #ifndef GATO_PCG_VSKEW
 #define GATO_PCG_VSKEW 4   // floats added to a block stride that is a multiple of 16 (64 bytes): see pcg_vec_stride
 #endif
+#ifndef GATO_STEP_DZ_ROWS
+#define GATO_STEP_DZ_ROWS 1
+#endif
 #ifndef GATO_SCHUR1_STAGE
 #define GATO_SCHUR1_STAGE 1
 #endif
@@ -3312,8 +3315,126 @@ GATO_DEV void order_by_pcg_iters(const Buffers& bf, int B, int* scratch /* 512 i
 
 // the step of trajectory b by a group of 8 N (first step of a solve: 9 N) threads, thread index t (the body of step_kernel).  exit_now: the
 // solve_ratio rule ended the loop in this iteration (bsqp.cuh:165): dz is still formed, the line search is not
+// dz of ONE trajectory with one lane per ROW (the step launch: TT = 8 N or 9 N lanes).  dz_knot gives a knot's state rows to one lane and its
+// control rows to another -- 2 N of the workgroup's lanes worked through ~180 loads and ~500 dependent instructions each while the others
+// waited at the barrier: 6 of the step launch's 25.8 us at C2, 11.6 of 36 at C5 (timed with the phases cut out one by one).  Here a lane
+// forms one entry of the stage-1 residual (state row x: q_x - ((-(A_k^T lambda_{k+2})_x) + lambda_{k+1,x}); control row: r_x + (B_k^T
+// lambda_{k+2})_x, schur_linsys.cuh:316-431) from ~20 loads -- consecutive lanes read consecutive columns of D -- and finishes every row
+// that needs nothing else (Q's qd half is diagonal, R is diagonal); the q half (Q_qq^-1 times the knot's nq residuals) follows after one
+// barrier from an LDS copy of the residuals.  EVERY load of both stages is issued up front: one memory round trip.  Each entry is the same
+// sequence of multiply-adds as in dz_knot (A_elem / B_elem with a lane-dependent column: selects instead of folded constants): same bits.
 template<class M>
-GATO_DEV void step_body(const Buffers& bf, int N, int B, int b, int t, float dt, int sqp_iter, bool exit_now, int adapt_rho, const float* __restrict__ drho_init,
+GATO_DEV void dz_rows(const Buffers& bf, int N, int b, int t, int TT, float dt, float* mirror, float* resb)
+{
+    constexpr int NQ = M::NQ, NX = 2 * NQ, NU = NQ, KS = NX + NU;
+    static_assert(NX <= 2 * NUM_ALPHAS && NU <= NUM_ALPHAS, "two state rows and one control row per lane at TT >= NUM_ALPHAS N");
+    const int traj = KS * N - NU;
+    const float* lam = bf.lambda + (size_t)b * (N + 2) * NX;
+    float* dzg = bf.dz + (size_t)b * traj;
+    const float h2 = half_dt_sq(dt);
+    const size_t b0 = (size_t)b * N;
+    // ---- loads: two state rows, one control row, one q-half row of stage 2 (indices clamped: loads are unconditional, stores are not)
+    int sk[2], sx[2];
+    bool son[2];
+    float sl1[2][NX], sD[2][NQ], slk[2], sq[2], sdi[2];
+#pragma unroll
+    for (int rep = 0; rep < 2; rep++) {
+        const int i = t + rep * TT;
+        son[rep] = i < N * NX;
+        const int ic = son[rep] ? i : 0;
+        sk[rep] = ic / NX;
+        sx[rep] = ic - sk[rep] * NX;
+        const size_t bk = b0 + sk[rep];
+#pragma unroll
+        for (int j = 0; j < NX; j++) sl1[rep][j] = lam[(size_t)(sk[rep] + 2) * NX + j];
+#pragma unroll
+        for (int j = 0; j < NQ; j++) sD[rep][j] = bf.D[bk * 3 * NQ * NQ + sx[rep] * NQ + j];   // column x of [dqdd/dq | dqdd/dqd]: what A_elem(., x) reads
+        slk[rep] = lam[(size_t)(sk[rep] + 1) * NX + sx[rep]];
+        sq[rep] = bf.q[bk * NX + sx[rep]];
+        sdi[rep] = bf.Qdi[bk * NQ + (sx[rep] >= NQ ? sx[rep] - NQ : 0)];
+    }
+    const bool con = t < N * NU;
+    const int ck = con ? t / NU : 0, cx = con ? t - ck * NU : 0;
+    float cl1[NX], cD[NQ], cr, cri;
+    {
+        const size_t bk = b0 + ck;
+#pragma unroll
+        for (int j = 0; j < NX; j++) cl1[j] = lam[(size_t)(ck + 2) * NX + j];
+#pragma unroll
+        for (int j = 0; j < NQ; j++) cD[j] = bf.D[bk * 3 * NQ * NQ + 2 * NQ * NQ + cx * NQ + j];   // column x of M^-1: what B_elem(., x) reads
+        cr = bf.r[bk * NU + cx];
+        cri = bf.Rdi[bk * NU + cx];
+    }
+    const bool qon = t < N * NQ;
+    const int qk = qon ? t / NQ : 0, qy = qon ? t - qk * NQ : 0;
+    float qi[NQ];
+#pragma unroll
+    for (int j = 0; j < NQ; j++) qi[j] = bf.Qqi[(b0 + qk) * NQ * NQ + j * NQ + qy];
+    // ---- stage 1
+#pragma unroll
+    for (int rep = 0; rep < 2; rep++) {
+        const int k = sk[rep], x = sx[rep];
+        const bool inner = k < N - 1;
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < NX; j++) {
+            // A_elem<NQ>(D, j, x, dt, h2) on the fetched column
+            const float d = sD[rep][j % NQ];
+            float val = (j == x) ? 1.0f : 0.0f;
+            if (j < NQ) {
+                if (x >= NQ && j == x - NQ) val += dt;
+                val += h2 * d;
+            } else {
+                val += dt * d;
+            }
+            s += sl1[rep][j] * val;
+        }
+        s = inner ? -s : 0.f;
+        const float scr = s + slk[rep];
+        const float res = sq[rep] - scr;
+        if (son[rep]) {
+            resb[k * NX + x] = res;
+            bf.q[(b0 + k) * NX + x] = res;
+            if (x >= NQ) {
+                const float out = -1.0f * (sdi[rep] * res);
+                dzg[(size_t)k * KS + x] = out;
+                mirror[(size_t)k * KS + x] = out;
+            }
+        }
+    }
+    if (con) {
+        const bool inner = ck < N - 1;
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < NX; j++) {
+            const float d = cD[j % NQ];
+            s += cl1[j] * ((j < NQ) ? h2 * d : dt * d);   // B_elem<NQ>(D, j, x, dt, h2)
+        }
+        const float su = cr - (-s);
+        const float out = -1.0f * (cri * su);
+        float* rk = bf.r + (b0 + ck) * NU;
+        if (inner) {
+            dzg[(size_t)ck * KS + NX + cx] = out;
+            mirror[(size_t)ck * KS + NX + cx] = out;
+            rk[cx] = su;
+        } else {
+            rk[cx] = 0.f;
+        }
+    }
+    __syncthreads();
+    // ---- stage 2: the q half, Q_qq^-1 times the knot's residuals
+    if (qon) {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < NQ; j++) s += qi[j] * resb[qk * NX + j];
+        const float out = -1.0f * s;
+        dzg[(size_t)qk * KS + qy] = out;
+        mirror[(size_t)qk * KS + qy] = out;
+    }
+}
+
+template<class M>
+GATO_DEV void step_body(const Buffers& bf, int N, int B, int b, int t, int TT, float dt, int sqp_iter, bool exit_now, int adapt_rho, const float* __restrict__ drho_init,
                         int last_iter, float* __restrict__ merit_init0, float* lds)
 {
     constexpr int NQ = M::NQ, NX = 2 * NQ, NU = NQ, KS = NX + NU;
@@ -3322,8 +3443,12 @@ GATO_DEV void step_body(const Buffers& bf, int N, int B, int b, int t, float dt,
     float* mer = lds + ((traj + 3) & ~3);   // NUM_ALPHAS merits, the current merit at [NUM_ALPHAS], wavefront partials from [12]
     if (b == 0 && t == 0) bf.ctrl->iters_done = sqp_iter + 1;
     const Costs cw = load_costs(bf, b);  // fetched now, used after the dz phase: the latency hides behind it
+#if GATO_STEP_DZ_ROWS
+    dz_rows<M>(bf, N, b, t, TT, dt, dzs, mer + 28);              // one lane per row; its stage-1 residuals [N nx] live behind the merits
+#else
     if (t < N) dz_knot<M, 1>(bf, N, b, t, dt, dzs);              // state rows
     else if (t < 2 * N) dz_knot<M, 2>(bf, N, b, t - N, dt, dzs);  // control rows
+#endif
     const int k = t % N, ai = t / N;
     // The loop breaks before the line search (bsqp.cuh:165); every workgroup takes the same branch.  `done` is raised by the NEXT
     // launch (kkt_kernel): set here it could stop a workgroup of this very launch before its dz.
@@ -3368,7 +3493,7 @@ __global__ __launch_bounds__(MAXT, MAXT == 512 ? 4 : 1) void step_kernel(Buffers
         order_by_pcg_iters(bf, B, reinterpret_cast<int*>(lds));
         return;
     }
-    step_body<M>(bf, N, B, b, t, dt, sqp_iter, (float)bf.num_solved[sqp_iter] >= thresh, adapt_rho, drho_init, last_iter, merit_init0, lds);
+    step_body<M>(bf, N, B, b, t, (int)blockDim.x, dt, sqp_iter, (float)bf.num_solved[sqp_iter] >= thresh, adapt_rho, drho_init, last_iter, merit_init0, lds);
 }
 
 // =========================================================================================================================
@@ -3503,7 +3628,7 @@ __global__ __launch_bounds__(256, 2) void sqp_pair_kernel(int slot, float* xu_io
         for (int h = 0; h < 2; h++) {
             if (h == 0 || has1) {
 #ifndef PAIR_NO_STEP
-                if (opaque_true()) step_body<M>(phase_view(slot, xu_io, x_s_in, ref_in), fresh_s(N_), fresh_s(B_), fresh_s(h ? pb1 : pb0), fresh_v(t0), dt, (int)it, exit_now, adapt_rho,
+                if (opaque_true()) step_body<M>(phase_view(slot, xu_io, x_s_in, ref_in), fresh_s(N_), fresh_s(B_), fresh_s(h ? pb1 : pb0), fresh_v(t0), 256, dt, (int)it, exit_now, adapt_rho,
                                                 drho_init, last, nullptr, lds);
 #endif
             }

@@ -689,7 +689,7 @@ static bool step_fused(const GatoSolver* s)
 template<class M> static void launch_step(GatoSolver* s, hipStream_t st, float dt, int sqp_iter, int last, bool first = false)
 {
     const float thresh = exit_threshold(s);
-    size_t lds = (size_t)(((s->traj + 3) & ~3) + 12 + 16) * sizeof(float);   // the step, 8 + 1 merits, 16 wavefront partials
+    size_t lds = (size_t)(((s->traj + 3) & ~3) + 12 + 16 + s->N * s->nx) * sizeof(float);   // the step, 8 + 1 merits, 16 wavefront partials, dz_rows' residuals
     const int T = (NUM_ALPHAS + (first ? 1 : 0)) * s->N;
     float* init0 = first ? s->d_merit_init0 : nullptr;
     const int extra = s->pcg_rounds > 1 ? 1 : 0;   // one more workgroup re-orders the trajectories for the next PCG launch
