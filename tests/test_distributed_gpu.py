@@ -136,13 +136,14 @@ def test_one_rank_communicator_through_the_same_entry_points():
     r = s.solve(pr["xu"], 0.01, pr["x_s"], pr["ref"])
     for k in ("XU", "final_merit", "pcg_iters_all", "ls_step_size", "kkt_converged"):
         np.testing.assert_array_equal(r[k], plain[k], err_msg=k)
-    assert s.shard_stats() == {"deferred_solves": 1, "replays": 0}   # the default: ONE ncclAllReduce of the count vector behind the solve
+    graph = os.environ.get("GATO_GRAPH", "0") not in ("", "0")       # a captured solve cannot take the host look: it shares the count per iteration
+    assert s.shard_stats() == {"deferred_solves": 0 if graph else 1, "replays": 0}   # the default: ONE ncclAllReduce of the count vector behind the solve
     s.set_solved_count_mode("per_iteration")                          # round 3's form: a 4-byte ncclAllReduce in every SQP iteration
     s.reset_dual(); s.reset_rho()
     r = s.solve(pr["xu"], 0.01, pr["x_s"], pr["ref"])
     for k in ("XU", "final_merit", "pcg_iters_all", "ls_step_size", "kkt_converged"):
         np.testing.assert_array_equal(r[k], plain[k], err_msg=k)
-    assert s.shard_stats() == {"deferred_solves": 1, "replays": 0}
+    assert s.shard_stats() == {"deferred_solves": 0 if graph else 1, "replays": 0}
     dev = torch.device("cuda", 0)
     pk = PackedResults(B, s.traj, 1, dev)
     pk.xu.copy_(torch.from_numpy(r["XU"]).to(dev))
@@ -207,7 +208,8 @@ def test_sharded_exit_rule_against_the_unsharded_solve(ratio, mode):
         np.testing.assert_array_equal(s.read("rho"), one.read("rho")[lo:hi])
         np.testing.assert_array_equal(s.read("lambda").reshape(hi - lo, -1), one.read("lambda").reshape(B, -1)[lo:hi])
         st = s.shard_stats()
-        if mode == "deferred":   # the rule fires at ratio 0.5 (replay) and never at ratio 1 (the speculative run IS the result)
+        if mode == "deferred" and os.environ.get("GATO_GRAPH", "0") in ("", "0"):   # (a suite run under GATO_GRAPH=1 captures every solve: per-iteration counts)
+            # the rule fires at ratio 0.5 (replay) and never at ratio 1 (the speculative run IS the result)
             assert st == {"deferred_solves": 1, "replays": 1 if ratio == 0.5 else 0}, st
         else:
             assert st["deferred_solves"] == 0, st
