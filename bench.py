@@ -6,7 +6,8 @@
 
 One step = one pass of the hot path over one batch: reset_dual() + reset_rho() + a full `BSQP::solve` (max_sqp_iters = 10, solve_ratio = 1,
 DEFAULT_SOLVER_PARAMS otherwise) on B = 1024 trajectories per GPU, inputs already resident in HBM, plus -- for N > 1 -- the
-solved count shared per SQP iteration (4-byte ncclAllReduce inside the solve) and the all-gather of iterates and merits over xGMI.
+solved count of the exit rule (deferred: ONE ncclAllReduce of the per-iteration count vector behind a speculative solve, an exact replay if the
+rule fired; GATO_SOLVED_COUNT=periter: a 4-byte ncclAllReduce in every SQP iteration) and the all-gather of iterates and merits over xGMI.
 value = sum over ranks of B * iterations / wall time (max over ranks).  Rank 0 prints ONE JSON line.
 
     --workload hparam --plant iiwa14 --knots 64 --batch 512     BASELINE config C5 (the hyper-parameter sweep): rank g solves shard g =
@@ -425,7 +426,9 @@ def main():
         "config": {"workload": "%s N=%d batch=%d per GPU (global %d), %s, %d SQP iterations per solve, reset_dual+reset_rho per solve"
                                % (plant, N, B, world * B, what, iters),
                    "plant": plant, "knot_points": N, "batch_per_gpu": B, "global_batch": world * B, "sqp_iters_per_solve": int(iters),
-                   "mean_pcg_iters": float(st["pcg_iters_all"].mean()), "parallelism": "batch-sharded x%d, solved count shared per SQP iteration, one packed all_gather of iterates + merits per solve, overlapped with the next solve" % world},
+                   "mean_pcg_iters": float(st["pcg_iters_all"].mean()), "parallelism": ("one GPU: the whole batch in one solver handle" if world == 1 else
+                                   "batch-sharded x%d (one process per GPU), the solved count of the exit rule reduced ONCE per solve behind a speculative solve "
+                                   "(multi_gpu.solved_count), one packed all_gather of iterates + merits per solve, overlapped with the next solve" % world)},
         "roofline": {"bound": "valu" if top is valu else "hbm", "kernel": dom, "achieved": top["achieved"], "peak": top["peak"], "unit": top["unit"],
                      "frac": top["frac"], "traffic": traffic, "hbm": hbm, "valu": valu, "pmc": pmc, "avg_launch_us": per_launch_us[dom],
                      "stage_us_per_solve": {k: round(v, 1) for k, v in stage_acc.items()},
