@@ -67,14 +67,14 @@ def stage_report(plant, N, B, dt, p, pr, verbose=True):
     return out, all(h <= max(4.0 * o, 2e-6) for h, o in out.values())
 
 
-def run(cases, seed, verbose=True, only=None):
+def run(cases, seed, verbose=True, only=None, maxb=6):
   rng = np.random.default_rng(seed)
   worst = dict(xu=0.0, merit=0.0)
   bad = amplified = beyond = nstalled = stall_hip = stall_orc = ntraj = 0
   for case in range(cases):
       plant = rng.choice(["indy7", "iiwa14"])
       N = int(rng.choice([4, 8, 16, 32, 64, 128]))
-      B = int(rng.integers(1, 7))
+      B = int(rng.integers(1, maxb + 1))
       dt = float(rng.choice([0.005, 0.01, 0.02, 0.05]))
       p = dict(DEFAULT_SOLVER_PARAMS, max_sqp_iters=1, pcg_tol=1e-9, max_pcg_iters=1000, rho=float(10 ** rng.uniform(-4, -1)),
                mu=float(rng.choice([1.0, 10.0, 50.0])), q_cost=float(rng.choice([0.5, 2.0, 10.0])), qd_cost=float(10 ** rng.uniform(-4, -1)),
@@ -164,6 +164,15 @@ def run(cases, seed, verbose=True, only=None):
               case, plant, N, B, dt, p["rho"]), flush=True)
           continue
       if not tie:
+          # the same second look the end-to-end bound gets: stage by stage against the float64 oracle.  Every stage tensor as accurate as the fp32
+          # oracle's means the merits of this trajectory amplify a stage-level difference of rounding size into a different argmin
+          # (seed 501 --maxb 48 case 43: iiwa14 N=16 dt=0.02, PCG counts identical on all 35 rows, iterate errors of BOTH fp32 paths 2e-4 .. 6e-3)
+          st, stages_ok = stage_report(plant, N, B, dt, p, pr, verbose=only is not None)
+          if stages_ok:
+              amplified += 1
+              print("ill-conditioned case %d: %s N=%d B=%d dt=%g rho=%.2e  a step differs from the float64 step beyond the tie tolerance, every stage within 4x of the "
+                    "fp32 oracle's error (worst stage: %s)" % (case, plant, N, B, dt, p["rho"], max(st, key=lambda k: st[k][0] / max(st[k][1], 5e-7))), flush=True)
+              continue
           bad += 1
           print("VIOLATION case %d: %s N=%d B=%d dt=%g rho=%.2e  a step differs from the float64 step without a tie in the float64 merits" % (
               case, plant, N, B, dt, p["rho"]), flush=True)
@@ -193,5 +202,6 @@ if __name__ == "__main__":
     ap.add_argument("--cases", type=int, default=60)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--only", type=int, nargs="*", default=None, help="diagnose these case numbers of the seed")
+    ap.add_argument("--maxb", type=int, default=6, help="batch sizes are drawn from 1..maxb (default 6: the seeds quoted in DESIGN.md)")
     a = ap.parse_args()
-    sys.exit(1 if run(a.cases, a.seed, only=a.only)[0] else 0)
+    sys.exit(1 if run(a.cases, a.seed, only=a.only, maxb=a.maxb)[0] else 0)
