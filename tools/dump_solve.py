@@ -5,7 +5,7 @@ from gato_amd.bsqp.config import DEFAULT_SOLVER_PARAMS
 from gato_amd.bsqp.workloads import fig8_problem
 from gato_amd._lib import NativeSolver
 out = {}
-for (plant, N, B) in (("iiwa14", 128, 256), ("iiwa14", 64, 37), ("indy7", 32, 1024), ("indy7", 4, 3), ("indy7", 8, 5), ("indy7", 128, 3), ("iiwa14", 16, 9)):
+for (plant, N, B) in (("iiwa14", 128, 256), ("iiwa14", 64, 37), ("indy7", 32, 1024), ("indy7", 4, 3), ("indy7", 8, 5), ("indy7", 128, 3), ("iiwa14", 16, 9), ("iiwa14", 32, 70), ("indy7", 64, 40)):
     pr = fig8_problem(plant, N, B, f_ext_std=2.0 if N == 8 else 0.0)
     s = NativeSolver(plant, N, B, dt=0.01, **dict(DEFAULT_SOLVER_PARAMS, max_sqp_iters=5))
     s.set_f_ext_batch(pr["f_ext"])
