@@ -49,6 +49,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));   // a pair of reals: o
 #ifndef GATO_STEP_DZ_ROWS
 #define GATO_STEP_DZ_ROWS 1
 #endif
+#ifndef GATO_SCHUR1_GJ_LDS
+#define GATO_SCHUR1_GJ_LDS 1
+#endif
 #ifndef GATO_SCHUR1_STAGE
 #define GATO_SCHUR1_STAGE 1
 #endif
@@ -1272,11 +1275,29 @@ __global__ __launch_bounds__(256) void schur1_kernel(Buffers bf, int N, int B, f
 #pragma unroll
         for (int p = 0; p < NX; p++) {
             float prow[NX];
+            const bool owner = (y == p);
+            if constexpr (STAGE && GATO_SCHUR1_GJ_LDS) {
+                // the pivot row through 16 floats of the wavefront's LDS slice (free between the staged copies) instead of fourteen ds_bpermute:
+                // its owner writes it (four stores), everybody reads it back as a broadcast (four 16-byte reads); LDS operations of one
+                // wavefront execute in order, the same values arrive
+                float* slot = wst + (grp & 3) * 16;
+                if (owner) {
 #pragma unroll
-            for (int c = 0; c < NX; c++) prow[c] = __shfl(th[c], p, 16);
+                    for (int c = 0; c < NX; c += 2) *reinterpret_cast<real2*>(slot + c) = make_real2(th[c], th[c + 1]);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+                for (int c = 0; c < NX; c += 2) {
+                    const real2 v = *reinterpret_cast<const real2*>(slot + c);
+                    prow[c] = v.x; prow[c + 1] = v.y;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            } else {
+#pragma unroll
+                for (int c = 0; c < NX; c++) prow[c] = __shfl(th[c], p, 16);
+            }
             const float pvInv = 1.0f / prow[p];
             const float f = th[p] * pvInv;
-            const bool owner = (y == p);
 #pragma unroll
             for (int c = 0; c < NX; c++) {
                 float x, yv;
