@@ -205,6 +205,18 @@ class OracleSolver:
         ptr = self.L.orc_buf(self.h, b"dz")
         np.ctypeslib.as_array(ptr, shape=(self.B * self.traj,))[:] = np.asarray(dz, self.dtype).reshape(-1)
 
+    def set_buf(self, name, arr):
+        """overwrite a stage buffer (teacher-forced stage tests: the line search from a GIVEN merit table, ...)"""
+        shape = (self.B,) + tuple(self._dim(d) for d in self.SHAPES[name])
+        n = int(np.prod(shape))
+        np.ctypeslib.as_array(self.L.orc_buf(self.h, name.encode()), shape=(n,))[:] = np.asarray(arr, self.dtype).reshape(-1)
+
+    def line_search(self, xu):
+        """lineSearchAndUpdateBatchedKernel (line_search.cuh:13-98) on the solver's merit table / merit_cur / rho / drho / dz; returns the new xu"""
+        xu = np.array(xu, dtype=self.dtype, order="C").reshape(self.B, self.traj)
+        self.L.orc_line_search(self.h, xu.ctypes.data_as(C.POINTER(self.L._ft)))
+        return xu
+
     def setup_kkt(self, xu, x_s, ref, dt):
         (_, a), (_, b), (_, c) = _f(xu, self.L), _f(x_s, self.L), _f(ref, self.L)
         self.L.orc_setup_kkt(self.h, a, b, c, dt)
