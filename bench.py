@@ -12,6 +12,10 @@ value = sum over ranks of B * iterations / wall time (max over ranks).  Rank 0 p
 
     --workload hparam --plant iiwa14 --knots 64 --batch 512     BASELINE config C5 (the hyper-parameter sweep): rank g solves shard g =
                                                                 cost tuple g of the notebook's grid, per-trajectory rho, dt 0.05, mu 1, pcg_tol 1e-3
+    --rehearse-one-device    N > 1 ranks on a box with ONE GPU (a rehearsal of the world > 1 branch below, never a measurement): every rank
+                             uses cuda:0, torch.distributed runs on gloo, RCCL refuses the duplicate device inside gato_comm_init, so the
+                             verified fallback takes over (results through torch.distributed, the other shards' solved counts handed to
+                             the library as zeros) -- every line of the multi-rank path runs except RCCL's own kernels
 For N > 1 the line also carries per_rank_ms (min / median / max of the ranks' own loop times), gather_ms (event-timed on the communication
 stream) and solve_ms_without_gather, so that an efficiency below 1 can be attributed to skew, to the collective, or to RCCL's kernels
 taking CUs from the next solve.
@@ -164,6 +168,8 @@ def main():
     ap.add_argument("--torch-gather", action="store_true", help="N > 1: gather through torch.distributed instead of the library's own communicator")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=1024)
+    ap.add_argument("--rehearse-one-device", action="store_true",
+                    help="N > 1 ranks sharing cuda:0 over gloo: exercises the multi-rank code path on a 1-GPU box; the value is not a scaling number")
     a = ap.parse_args()
 
     import torch
@@ -175,11 +181,18 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (a.gpus, world, a.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (the product has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    rehearse = bool(a.rehearse_one_device) and world > 1
+    dev_index = 0 if rehearse else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    # bookkeeping collectives (flags, times) run on `cdev`: the device under RCCL, the host under gloo (the rehearsal)
+    cdev = torch.device("cpu") if rehearse else dev
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from gato_amd._lib import NativeSolver
     from gato_amd.bsqp.config import DEFAULT_SOLVER_PARAMS
@@ -221,7 +234,7 @@ def main():
         # the library's own communicator (gato_comm_init): the solved count of the exit rule is shared per SQP iteration inside the solve
         # and the results travel by ncclAllGather on it.  Checked before use: every rank gathers a known pattern; if ANY rank fails the
         # whole job falls back to torch.distributed for the results (and to per-shard counting, exact here: fig-8 / sweep rows do not converge)
-        ok_t = torch.ones(1, device=dev)
+        ok_t = torch.ones(1, device=cdev)
         try:
             connect(solver)   # agrees on RCCL's availability across the ranks BEFORE any rank enters ncclCommInitRank: fails on all ranks or none
             probe = torch.full((4,), float(rank + 1), device=dev)
@@ -241,7 +254,7 @@ def main():
             check_sharded_params(params["solve_ratio"], world, coupled=True)
         else:
             # explicit fallback: no rank has a usable communicator.  The shards count their own rows against the WHOLE batch's threshold (the
-            # other shards' counts taken as zero): exact exactly as long as no trajectory converges -- verified after the run (`ok` below)
+            # other shards' counts taken as zero): exact as long as the whole batch's rule never fires -- verified after the run (`checks` below)
             try:
                 solver.comm_destroy()
             except Exception:   # noqa: BLE001
@@ -290,6 +303,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if world > 1:
+        # which rows this rank solves, said by the rank itself: its first reference point and first start state go onto the line (multi_gpu.shards)
+        mine = torch.tensor([float(rank), float(pr["ref"][0, 0]), float(pr["ref"][0, 1]), float(pr["ref"][0, 2]), float(pr["x_s"][0, 0]),
+                             float(params["q_cost"]), float(params["qd_cost"]), float(params["u_cost"]), float(params["N_cost"])], dtype=torch.float64, device=cdev)
+        shard_rows = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(shard_rows, mine)
+        shard_rows = torch.stack(shard_rows).cpu().numpy()
     for _ in range(a.warmup):
         step()
     sync()
@@ -304,12 +324,12 @@ def main():
     t = time.perf_counter() - t0
     multi = {}
     if world > 1:
-        tt = torch.tensor([t], dtype=torch.float64, device=dev)
+        tt = torch.tensor([t], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         t = float(tt.item())
-        own = [torch.zeros(2, dtype=torch.float64, device=dev) for _ in range(world)]
+        own = [torch.zeros(2, dtype=torch.float64, device=cdev) for _ in range(world)]
         g_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in gather_ev])) if gather_ev else 0.0
-        dist.all_gather(own, torch.tensor([1e3 * t_own / a.steps, g_ms], dtype=torch.float64, device=dev))
+        dist.all_gather(own, torch.tensor([1e3 * t_own / a.steps, g_ms], dtype=torch.float64, device=cdev))
         own = torch.stack(own).cpu().numpy()
         # the same loop with the gather switched off (untimed for the headline): what the collective and its kernels cost the solves
         sync()
@@ -319,16 +339,21 @@ def main():
             step(gather=False)
         e1.record(main)
         sync()
-        ng = torch.tensor([e0.elapsed_time(e1) / max(2, a.steps // 4)], dtype=torch.float64, device=dev)
+        ng = torch.tensor([e0.elapsed_time(e1) / max(2, a.steps // 4)], dtype=torch.float64, device=cdev)
         dist.all_reduce(ng, op=dist.ReduceOp.MAX)
         sh = solver.shard_stats()
         multi = {"collective": collective,
                  "solved_count": ("deferred" if os.environ.get("GATO_SOLVED_COUNT", "") != "periter" else "per_iteration") if coupled else "per shard (no communicator)",
                  "solved_count_detail": ("speculative solve + ONE ncclAllReduce of the per-iteration count vector per solve; %d of %d solves replayed exactly"
-                                         % (sh["replays"], sh["deferred_solves"])) if coupled else "shards count alone: exact while nothing converges (checked)",
+                                         % (sh["replays"], sh["deferred_solves"])) if coupled else "shards count alone: exact while the whole batch's exit rule never fires (checked: solution_checks)",
                  "per_rank_ms": {"min": float(own[:, 0].min()), "median": float(np.median(own[:, 0])), "max": float(own[:, 0].max())},
                  "gather_ms": {"mean_over_ranks": float(own[:, 1].mean()), "max_over_ranks": float(own[:, 1].max())},
-                 "solve_ms_without_gather": float(ng.item())}
+                 "solve_ms_without_gather": float(ng.item()),
+                 "shards": [{"rank": int(r[0]), "first_ref_xyz": [float(r[1]), float(r[2]), float(r[3])], "first_q0": float(r[4]),
+                             "cost_tuple": {"q_cost": float(r[5]), "qd_cost": float(r[6]), "u_cost": float(r[7]), "N_cost": float(r[8])}} for r in shard_rows]}
+        if rehearse:
+            multi["rehearsal"] = ("%d ranks sharing ONE device over gloo: a run of the multi-rank code path, not a scaling measurement "
+                                  "(the solves of the ranks time-share the GPU)" % world)
 
     st = solver.stats()
     iters = st["iters_done"]
@@ -339,9 +364,14 @@ def main():
     stage_acc = solver.stage_times_us()
     solver.set_profiling(False)
     # every trajectory finite and none worse than it started (a sweep row whose rho makes every line search fail keeps its merit: equal)
-    ok = bool(np.all(np.isfinite(st["final_merit"])) and np.all(st["final_merit"] <= st["initial_merit"]) and np.any(st["final_merit"] < st["initial_merit"]))
+    checks = {"finite": bool(np.all(np.isfinite(st["final_merit"]))), "no_row_worse_than_it_started": bool(np.all(st["final_merit"] <= st["initial_merit"])),
+              "some_row_improved": bool(np.any(st["final_merit"] < st["initial_merit"]))}
     if world > 1 and not coupled:
-        ok = ok and not bool(np.any(st["kkt_converged"]))   # shards that count alone are exact only while nothing converges
+        # shards that count alone (the other shards' counts taken as zero against the WHOLE batch's threshold) never fire the rule; with solve_ratio = 1
+        # the true rule fires only once EVERY row of EVERY shard is converged, so a shard that still holds an unconverged row at the end proves the
+        # two agree (convergence flags are sticky: bsqp.cuh:153-156)
+        checks["uncoupled_shard_kept_an_unconverged_row"] = bool(params["solve_ratio"] >= 1.0 and not np.all(st["kkt_converged"]))
+    ok = all(checks.values())
     # a parity bit on the line itself (untimed tail; the oracle is the CHECKER here, never the thing measured): 16 rows spread over this rank's
     # batch, solved by the CPU oracle from the same reset state -- the first SQP iteration's decisions (line-search step, PCG count +-1, initial
     # merit) of the timed solves must be the oracle's.  Later iterations of a free-running fp32 solve are not comparable row by row.
@@ -368,9 +398,11 @@ def main():
             need = len(idx) if a.workload == "fig8" else len(idx) // 2
             parity = {"rows": int(len(idx)), "checker": "oracle/gato_oracle.c (fp32), first SQP iteration from the reset state",
                       "rows_on_the_oracles_step_or_a_tie": passed, "rows_pcg_iters_within_1": pcg_n, "rows_required": need, "initial_merit_rel_err": im}
-            ok = ok and passed >= need and pcg_n >= need and im < 1e-5
+            checks["parity_sample"] = bool(passed >= need and pcg_n >= need and im < 1e-5)
+            ok = ok and checks["parity_sample"]
         except Exception as e:   # noqa: BLE001
             parity = {"error": "%s: %s" % (type(e).__name__, e)}
+            checks["parity_sample"] = False
             ok = False
     if rank != 0:
         if world > 1:
@@ -436,6 +468,7 @@ def main():
                      "whole_iteration": {"algorithmic_bytes_per_traj_iter": iter_bytes,
                                          "hbm_frac": iter_bytes * value / world / 1e9 / HBM_PEAK_GBS}},
         "solution_ok": ok,
+        "solution_checks": checks,
         "parity_sample": parity,
     }
     if multi:

@@ -22,8 +22,9 @@ SYMBOLS = [
     "gato_plant_rk4", "gato_fk_placements", "gato_set_linear_solver", "gato_set_graph_mode",
     "gato_mpc_begin", "gato_mpc_step", "gato_mpc_get_best", "gato_plant_payload_rk4", "gato_mpc_set_payload", "gato_mpc_get_payload",
     "gato_comm_unique_id", "gato_comm_init", "gato_comm_destroy", "gato_gather_results", "gato_debug_set_remote_solved", "gato_abi_real_size",
-    "gato_set_solved_count_mode", "gato_get_shard_stats",
+    "gato_set_solved_count_mode", "gato_get_shard_stats", "gato_comm_available", "gato_abi_version",
 ]
+ABI_VERSION = 5   # GATO_ABI_VERSION of the include/gato_abi.h this binding was written against
 
 
 def _params_struct(ft, name):
@@ -36,7 +37,7 @@ def _params_struct(ft, name):
 def _mpc_struct(ft, name):
     """GatoMpcStep of include/gato_abi.h"""
     return type(name, (C.Structure,), {"_fields_": [
-        ("phases", C.c_int32), ("plant_steps", C.c_int32), ("sim_dt", ft), ("steps_per_knot", C.c_double), ("plant_wrench", ft * 6),
+        ("struct_size", C.c_uint32), ("phases", C.c_int32), ("plant_steps", C.c_int32), ("sim_dt", ft), ("steps_per_knot", C.c_double), ("plant_wrench", ft * 6),
         ("ref_window", C.POINTER(ft)), ("hyp_world", C.POINTER(ft)), ("select", C.c_int32), ("select_dt", ft), ("x", ft * 16), ("ee", ft * 3),
         ("best", C.c_int32), ("solve_us", C.c_double), ("errors", C.POINTER(ft)), ("plant_us", C.c_double)]})
 
@@ -131,6 +132,8 @@ def load(f64=False):
     L.gato_sim_forward_device.argtypes = [vp, vp, vp, vp, ft, vp]
     L.gato_last_error.restype = C.c_char_p
     L.gato_version.restype = C.c_char_p
+    if L.gato_abi_version() != ABI_VERSION:
+        raise GatoError("%s has ABI version %d, this binding expects %d (rebuild: make -C gato_amd/csrc)" % (path, L.gato_abi_version(), ABI_VERSION))
     if L.gato_abi_real_size() != C.sizeof(ft):
         raise GatoError("%s carries %d-byte reals, the binding expects %d" % (path, L.gato_abi_real_size(), C.sizeof(ft)))
     _libs[f64] = L
@@ -350,6 +353,7 @@ class NativeSolver:
     def mpc_step(self, advance=True, plan=True, plant_steps=0, sim_dt=0.001, steps_per_knot=1.0, plant_wrench=None, ref_window=None, hyp_world=None,
                  select=False, select_dt=0.0):
         io = self.L._MPC()
+        io.struct_size = C.sizeof(io)
         io.phases = (1 if advance else 0) | (2 if plan else 0)
         io.plant_steps, io.sim_dt, io.steps_per_knot = int(plant_steps), float(sim_dt), float(steps_per_knot)
         fw = self._f(np.zeros(6) if plant_wrench is None else plant_wrench, (6,))
@@ -380,6 +384,12 @@ class NativeSolver:
         buf = C.create_string_buffer(128)
         _chk(L.gato_comm_unique_id(buf), L)
         return buf.raw
+
+    @staticmethod
+    def comm_available(f64=False):
+        """None when librccl can be opened and has every entry point the library binds, else the reason; no RCCL call is made"""
+        L = load(f64)
+        return None if L.gato_comm_available() == 0 else L.gato_last_error().decode()
 
     def comm_init(self, unique_id, world_size, rank):
         """collective over all ranks: this solver becomes shard `rank` of a batch of world_size x B trajectories"""

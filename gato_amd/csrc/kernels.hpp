@@ -108,8 +108,6 @@ struct Buffers {
     uint32_t* num_solved;  // [max_iters]: trajectories counted as solved after outer iteration i (bsqp.cuh:142-163) -- over the WHOLE batch: what
                            // the exit rule reads.  On a sharded batch (gato_comm_init) the sum over the ranks of ...
     uint32_t* num_solved_w;  // ... this rank's own count, which the PCG kernels add to (the same array on a single GPU)
-    uint32_t* pcg_done;      // [max_iters]: workgroups of sqp_pair_kernel that have finished the PCG of outer iteration i (their counts are in)
-    uint32_t* pair_fin;      // [1]: workgroups of sqp_pair_kernel that have finished the solve (the last one re-orders the trajectories)
 };
 
 #define GATO_DEV_EARLY __device__ __forceinline__
@@ -609,20 +607,17 @@ template<class M, int g> GATO_DEV void kkt_dispatch(int task, const Buffers& bf,
 // after a barrier the whole workgroup copies the 64 blocks -- contiguous in global memory -- out with 16-byte stores of consecutive
 // lanes.  Written directly, every lane's 24-byte column pieces were separate 8-byte requests to different cache lines (54 per knot);
 // the request rate of those stores, not the arithmetic, bounded this kernel.
-// the assembly of the 64 consecutive knots [64 wg, 64 wg + 64) by the NT task-wavefronts of a workgroup (the body of kkt_kernel; sqp_pair_kernel
-// calls it for the two trajectories it owns)
-// PAIRED (sqp_pair_kernel, N = 32): the 64 lanes are the knots of the two trajectories pb0 (lanes 0-31) and pb1 (lanes 32-63; < 0: none) --
-// any two, not neighbours in the batch; their D blocks leave as two runs of 32 blocks.  The per-lane work is the same code either way.
-template<class M, bool PAIRED = false>
-GATO_DEV void kkt_body(const Buffers& bf, int N, int B, float dt, int row0, int wg, float* ldsD, int pb0 = 0, int pb1 = -1)
+// the assembly of the 64 consecutive knots [64 wg, 64 wg + 64) by the NT task-wavefronts of a workgroup (the body of kkt_kernel)
+template<class M>
+GATO_DEV void kkt_body(const Buffers& bf, int N, int B, float dt, int row0, int wg, float* ldsD)
 {
     constexpr int NQ = M::NQ, NX = 2 * NQ, NU = NQ, KS = NX + NU, NT = kkt_tasks<M>(), ND = 3 * NQ * NQ;
     const int lane = threadIdx.x & 63;
     const int task = threadIdx.x >> 6;  // wave-uniform
     const long total = (long)B * N;
     const long g = (long)wg * 64 + lane;
-    const bool valid = PAIRED ? (lane < 32 || pb1 >= 0) : g < total;       // lanes past the batch shadow knot (0,0) and store nothing
-    const int k = PAIRED ? (lane & 31) : (valid ? (int)(g % N) : 0), b = PAIRED ? (lane < 32 || pb1 < 0 ? pb0 : pb1) : (valid ? (int)(g / N) : 0);
+    const bool valid = g < total;       // lanes past the batch shadow knot (0,0) and store nothing
+    const int k = valid ? (int)(g % N) : 0, b = valid ? (int)(g / N) : 0;
     const bool last = (k == N - 1);
     const int traj = KS * N - NU;
     const int kx = last ? N - 2 : k;  // the terminal lane reads knot N-2
@@ -651,22 +646,12 @@ GATO_DEV void kkt_body(const Buffers& bf, int N, int B, float dt, int row0, int 
         }
     }
     __syncthreads();
-    if constexpr (PAIRED) {
-        constexpr int n4 = 32 * ND / 4;   // one trajectory's 32 blocks: 32 ND floats, 16-byte aligned on both sides
-        static_assert((32 * ND) % 4 == 0, "whole 16-byte pieces");
-        for (int h = 0; h < (pb1 >= 0 ? 2 : 1); h++) {
-            float* gD = bf.D + (size_t)(h ? pb1 : pb0) * N * ND;
-            const real4* src = reinterpret_cast<const real4*>(ldsD + (size_t)h * 32 * ND);
-            for (int i = threadIdx.x; i < n4; i += blockDim.x) reinterpret_cast<real4*>(gD)[i] = src[i];
-        }
-    } else {
-        const long first = (long)wg * 64;
-        const int cnt = (int)((total - first) < 64 ? (total - first) : 64);
-        const int nfl = cnt * ND, n4 = nfl / 4;
-        float* gD = bf.D + (size_t)first * ND;  // 64 ND floats per workgroup: 16-byte aligned
-        for (int i = threadIdx.x; i < n4; i += blockDim.x) reinterpret_cast<real4*>(gD)[i] = reinterpret_cast<const real4*>(ldsD)[i];
-        for (int i = 4 * n4 + threadIdx.x; i < nfl; i += blockDim.x) gD[i] = ldsD[i];
-    }
+    const long first = (long)wg * 64;
+    const int cnt = (int)((total - first) < 64 ? (total - first) : 64);
+    const int nfl = cnt * ND, n4 = nfl / 4;
+    float* gD = bf.D + (size_t)first * ND;  // 64 ND floats per workgroup: 16-byte aligned
+    for (int i = threadIdx.x; i < n4; i += blockDim.x) reinterpret_cast<real4*>(gD)[i] = reinterpret_cast<const real4*>(ldsD)[i];
+    for (int i = 4 * n4 + threadIdx.x; i < nfl; i += blockDim.x) gD[i] = ldsD[i];
 }
 
 template<class M>
@@ -1435,8 +1420,7 @@ GATO_DEV float wave_sum(float v)
 // block-wide sum; `part` has 16 slots (unused ones zeroed once by the caller), read back with four 16-byte LDS loads
 // PARTS = 16-byte groups that can hold a wavefront's partial (<= 4 PARTS wavefronts in the workgroup): the skipped ones are exact
 // zeros, so every PARTS gives the same bits.
-// tx: the thread's index inside the group of wavefronts that sums (the workgroup, or one trajectory's half of a two-trajectory workgroup:
-// sqp_pair_kernel -- then the barrier is still the workgroup's and both halves reach it in lock step)
+// tx: the thread's index inside the group of wavefronts that sums (the workgroup)
 template<int PARTS = 4> GATO_DEV float block_sum(float v, float* part, unsigned tx = threadIdx.x)
 {
     v = wave_sum(v);
@@ -1843,13 +1827,10 @@ template<int RPT, int NXT> GATO_DEV void rows_axpy(float (*acc)[NXT], const floa
 // FULL: every thread owns a row group (threads x RPT == N nx: N a multiple of 16 in the fused forms) -- the masks of idle lanes and the
 // exec-mask juggling around the LDS stores drop out of the iteration (14 of ~305 instructions)
 // The body of pcgc_kernel as a device function: `b` the trajectory, tx / TT the thread's index in / the size of the group of wavefronts that
-// works on it, `lds` that group's own LDS.  The launched kernel passes its workgroup.  LOCK (sqp_pair_kernel): TWO trajectories share one
-// workgroup, each on its own half of the threads with its own LDS; every barrier is the workgroup's, so the halves run in lock step -- a half
-// whose trajectory is converged (pcg.cuh:29-32), does not exist (odd batch) or has finished iterating keeps arriving at the barriers
-// (`flags`: two LDS words through which the halves agree on when BOTH are done) and stores nothing.  The arithmetic is the same code.
-template<class M, int RPT, int MAXT, bool FOLD, bool FUSE, bool PAIR, bool FULL, bool LOCK = false>
-GATO_DEV void pcgc_body(const Buffers& bf, int N, int B, int b, unsigned tx, unsigned TT, float* lds, uint32_t max_iters, int sqp_iter, int write_p, float dt,
-                        bool exists = true, int half = 0, volatile int* flags = nullptr)
+// works on it, `lds` that group's own LDS.  The launched kernel passes its workgroup.  (The lock-step form for two trajectories per workgroup
+// that the persistent loop of round 4 used is kept as tools/microbench/sqp_pair.patch.)
+template<class M, int RPT, int MAXT, bool FOLD, bool FUSE, bool PAIR, bool FULL>
+GATO_DEV void pcgc_body(const Buffers& bf, int N, int B, int b, unsigned tx, unsigned TT, float* lds, uint32_t max_iters, int sqp_iter, int write_p, float dt)
 {
     constexpr int NQ = M::NQ, NX = 2 * NQ, BR = 3 * NX, BROW = 3 * NX * NX;
     constexpr int PARTS = (FUSE || MAXT <= 256) ? 1 : (MAXT <= 512 ? 2 : 4);  // FUSE is only launched with <= 256 threads
@@ -1867,9 +1848,8 @@ GATO_DEV void pcgc_body(const Buffers& bf, int N, int B, int b, unsigned tx, uns
     const float abs_tol = 1e-6f;
     uint32_t iters = 0;
     const bool skip = bf.converged[b] != 0;  // pcg.cuh:29-32
-    static_assert(!LOCK || (!PAIR && FUSE && FOLD), "the lock-step form exists for the fused single-lane kernel");
 
-    if (LOCK || !skip) {
+    if (!skip) {
         const float eps = bf.pcg_tol[b];
         // PAIR: lanes t and t ^ 4 (the two quads of an 8-lane group) run the SAME row group through the prologue (tid is the lane's
         // index in the single-lane form) and then split its 3 nx columns for the iteration
@@ -2180,19 +2160,7 @@ GATO_DEV void pcgc_body(const Buffers& bf, int N, int B, int b, unsigned tx, uns
             loc += rv[u] * zv[u];
         }
         float rho = block_sum<PARTS>(loc, partA, tx);
-        // LOCK: the loop below is the launched kernel's, untouched (its four barriers per iteration are the workgroup's: the other half is
-        // at the same ones, in its own loop or in the drain loop behind this one)
-        bool entered = !(fabsf(rho) < abs_tol);
-        if constexpr (LOCK) {
-            entered = entered && exists && !skip;
-            if (tx == 0) flags[half] = entered ? 1 : 0;
-            // In the persistent loop a SIMD's other wavefront belongs to another workgroup in ANOTHER phase (assembly and step are issue-hungry,
-            // this loop mostly waits for LDS round trips and barriers): served first, the iteration keeps close to its lone rate and the
-            // throughput phases fill the slots it leaves
-#ifndef GATO_PAIR_NO_PRIO
-            __builtin_amdgcn_s_setprio(3);
-#endif
-        }
+        const bool entered = !(fabsf(rho) < abs_tol);
         if (entered) {
             const float rho_init = fabsf(rho);
             for (uint32_t it = 0; it < max_iters; it++) {
@@ -2231,25 +2199,9 @@ GATO_DEV void pcgc_body(const Buffers& bf, int N, int B, int b, unsigned tx, uns
             }
             if (have) store_vec<RPT, RPT>(lam + NX + rr, xv);
         }
-        if constexpr (LOCK) {
-            // drain: this half is done (or never iterated); it keeps the other half company at its barriers -- four per iteration -- until
-            // that one is done too: a half clears its flag after its last iteration, both read the other's flag behind the first barrier of
-            // a round, so both leave behind the same barrier
-            if (tx == 0) flags[half] = 0;
-            for (;;) {
-                __syncthreads();
-                if (!flags[half ^ 1]) break;
-                __syncthreads();
-                __syncthreads();
-                __syncthreads();
-            }
-#ifndef GATO_PAIR_NO_PRIO
-            __builtin_amdgcn_s_setprio(0);
-#endif
-        }
         }
     }
-    if (tx == 0 && exists) {
+    if (tx == 0) {
         bf.pcg_iters[b] = iters;
         bf.st_pcg_iters[(size_t)sqp_iter * B + b] = (int32_t)iters;
         int conv = skip ? 1 : 0;
@@ -3515,172 +3467,6 @@ __global__ __launch_bounds__(MAXT, MAXT == 512 ? 4 : 1) void step_kernel(Buffers
         return;
     }
     step_body<M>(bf, N, B, b, t, (int)blockDim.x, dt, sqp_iter, (float)bf.num_solved[sqp_iter] >= thresh, adapt_rho, drho_init, last_iter, merit_init0, lds);
-}
-
-// =========================================================================================================================
-// The whole SQP loop of TWO trajectories in one persistent workgroup (round 4; indy7, N = 32: the headline configuration).
-//
-// The launched loop (solver.hip:enqueue_solve) synchronises the whole batch three times per SQP iteration, and every PCG launch lasts as long
-// as its slowest trajectory iterates: sum_i max_b iterations = 1120 per 10-iteration solve at C2 against 438 for the average trajectory and
-// 863 for the hardest one -- the chip idles behind a handful of outliers (the 99th percentile of an iteration's counts is 43..122, its maximum
-// 50..200), and while all trajectories ARE in the same phase their wavefronts compete for the same unit (issue slots in the assembly / step
-// phases, LDS round trips in the PCG).  Here workgroup j owns trajectories 2j and 2j + 1 for the whole solve:
-//     assembly of their 64 knots (the four task-wavefronts of kkt_kernel's workgroup: exactly that mapping)
-//  -> fused Schur + PCG of both, each on two of the four wavefronts, in lock step on the workgroup's barriers (pcgc_body<.., LOCK>)
-//  -> the exit rule -> step of trajectory 2j, step of trajectory 2j + 1 (8 N = 256 lanes each: the workgroup) -> next assembly ...
-// with NO batch-wide synchronisation: a workgroup whose trajectories need few PCG iterations runs ahead, neighbours on a SIMD are in
-// different phases.  Every phase is the device function the launched kernels call: the same bits.
-//
-// The exit rule (bsqp.cuh:165: stop before the line search once num_solved >= batch x solve_ratio) is the one thing that couples the
-// trajectories.  With solve_ratio >= 1 (the launch condition) the rule can only fire when EVERY trajectory is converged, so a workgroup that
-// holds an unconverged one knows the answer without asking; only a workgroup whose trajectories are all converged waits for the whole
-// batch's count: it spins on pcg_done[it] (agent scope; every workgroup is resident: the launch condition 2 x waves <= the chip's slots).
-// =========================================================================================================================
-// Two things the compiler must be kept from doing to a loop around whole phases, each of which fills the register file on its own:
-//  * the buffer table as a by-value kernel argument stays live across the whole loop (30 pointers: 141 SGPR spills into vector lanes, and
-//    behind them 432 bytes of scratch per lane, two reloads inside the PCG iteration); through a pointer to global memory it is fetched with
-//    VECTOR loads (the scalar cache is not coherent with stores, so only provably constant memory is read through it): two VGPRs per
-//    pointer.  It lives in CONSTANT memory (g_pair_tab, one slot per solver handle; s_load) and is re-read behind an opaque move at the
-//    start of every phase;
-//  * everything a phase derives from the thread index, N, B and the trajectory is invariant in the outer loop, gets hoisted out of it and
-//    then lives across every OTHER phase too (156 bytes of scratch for the PCG alone).  Each phase starts from freshly "laundered" copies
-//    (an empty asm the optimiser cannot look through), so its address arithmetic is born and dies inside it, as in the launched kernels.
-constexpr int PAIR_SLOTS = 32;
-__constant__ Buffers g_pair_tab[PAIR_SLOTS];
-GATO_DEV Buffers phase_view(int slot, float* xu, const float* x_s, const float* ref)
-{
-    asm volatile("" : "+s"(slot));
-    Buffers b = g_pair_tab[slot];
-    b.xu = xu; b.x_s = x_s; b.ref = ref;
-    return b;
-}
-GATO_DEV int fresh_v(int v) { asm volatile("" : "+v"(v)); return v; }
-GATO_DEV int fresh_s(int v) { asm volatile("" : "+s"(v)); return v; }
-
-template<class M>
-__global__ __launch_bounds__(256, 2) void sqp_pair_kernel(int slot, float* xu_io, const float* __restrict__ x_s_in, const float* __restrict__ ref_in, int N_, int B_, float dt,
-                                                          uint32_t iters, uint32_t max_pcg_iters, float thresh, int adapt_rho, const float* __restrict__ drho_init,
-                                                          float* __restrict__ merit_init0, unsigned long long* __restrict__ trace)
-{
-    constexpr int NQ = M::NQ, NX = 2 * NQ, NU = NQ, KS = NX + NU;
-    static_assert(NX == 12 && kkt_tasks<M>() == 4, "two 32-knot trajectories = the 64 knots of one assembly workgroup, 4 task wavefronts");
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    __shared__ int flags[4];   // [0..1] the halves' PCG lock step, [2] the exit decision
-    const int t0 = threadIdx.x;
-    // `half` is wavefront-uniform; said so explicitly (v_readfirstlane), the trajectory index and every base address derived from it are scalar
-    // registers, as in the launched kernel where the trajectory comes from blockIdx
-    const int half0 = __builtin_amdgcn_readfirstlane(t0 >> 7);
-    // The pairing: order[] lists the trajectories hardest first (by the PCG iterations of the PREVIOUS solve on this handle: the last workgroup
-    // of a solve sorts them; the identity before the first one).  Workgroup j takes the j-th hardest and the j-th EASIEST: the halves run
-    // their PCG in lock step, so a workgroup lasts sum_i max(it0_i, it1_i) iterations -- next to an easy partner that is the hard
-    // trajectory's own count, and once the partner is done the barriers no longer wait for it (0.94 instead of 1.14 us per iteration,
-    // measured); paired with its neighbour in the batch the hardest workgroup of C2 ran 1023 iterations where its hardest trajectory needs 863.
-    // The results do not depend on the pairing (tests/test_persistent_gpu.py).
-    const int nW = gridDim.x, wg0 = blockIdx.x;
-    int pb0, pb1;
-    {
-        const Buffers bf = phase_view(slot, xu_io, x_s_in, ref_in);
-        pb0 = __builtin_amdgcn_readfirstlane(bf.order[wg0]);
-        pb1 = (wg0 < B_ / 2) ? __builtin_amdgcn_readfirstlane(bf.order[B_ - 1 - wg0]) : -1;
-    }
-    // issue priority outside the PCG loop by rank: the chain of the hardest workgroups is what the launch waits for
-    const int base_prio = wg0 < nW / 16 ? 2 : (wg0 < nW / 4 ? 1 : 0);
-    auto set_base_prio = [&]() {
-#ifndef GATO_PAIR_NO_PRIO
-        if (base_prio == 2) __builtin_amdgcn_s_setprio(2);
-        else if (base_prio == 1) __builtin_amdgcn_s_setprio(1);
-        else __builtin_amdgcn_s_setprio(0);
-#endif
-    };
-    set_base_prio();
-    // trace (GATO_PAIR_TRACE, measurement builds of the host only): [wg][0] start, [wg][1 + 2 it] after the PCG of iteration it, [wg][2 + 2 it] after its steps
-    if (trace && t0 == 0) trace[(size_t)blockIdx.x * 32] = wall_clock64();
-
-    if (opaque_true()) {
-        // merit of the initial iterate (bsqp.cuh:116-118) with merit_kernel<M, 1>'s lanes and sum tree: lane (b, k) = (2 wg + l / N, l % N)
-        const Buffers bf = phase_view(slot, xu_io, x_s_in, ref_in);
-        const int t = fresh_v(t0), N = fresh_s(N_);
-        if (t < 64) {
-            const int k = t & 31;
-            const bool live = t < 32 || pb1 >= 0;
-            const int b = (t < 32 || pb1 < 0) ? pb0 : pb1;
-            float m = merit_term<M>(bf, load_costs(bf, b), N, b, k, 1.0f, 0, bf.dz + (size_t)b * (KS * N - NU), dt);
-            m = seg_sum(m, N, nullptr);
-            if (live && k == 0) { bf.merit_cur[b] = m; merit_init0[b] = m; }
-        }
-    }
-    for (uint32_t it = 0; it < iters; it++) {
-#ifndef PAIR_NO_KKT
-        if (opaque_true()) kkt_body<M, true>(phase_view(slot, xu_io, x_s_in, ref_in), fresh_s(N_), fresh_s(B_), dt, 1, 0, lds, fresh_s(pb0), fresh_s(pb1));
-#endif
-        __syncthreads();   // the assembly's global stores are visible to the whole workgroup; its LDS is free
-#ifndef PAIR_NO_PCG
-        if (opaque_true()) {
-            const int t = fresh_v(t0), half = fresh_s(half0), N = fresh_s(N_), B = fresh_s(B_), q0 = fresh_s(pb0), q1 = fresh_s(pb1);
-            const bool has1 = q1 >= 0;
-            const int bh = (half == 0 || !has1) ? q0 : q1;   // a workgroup without a second trajectory runs the first one twice (the copy stores nothing)
-            // LDS: [half 0's PCG region | half 1's]; the assembly's 64 D blocks and the step's dz + merits reuse it (phases are separated by barriers)
-            const int pcg_words = (2 * (N + 2) * NX + 36) + 2 * N * NX * NX;
-            pcgc_body<M, 3, 256, true, true, false, true, true>(phase_view(slot, xu_io, x_s_in, ref_in), N, B, bh, t & 127, 128, lds + (size_t)half * pcg_words, max_pcg_iters,
-                                                                (int)it, 0, dt, half == 0 || has1, half, flags);
-        }
-#endif
-        set_base_prio();
-        __syncthreads();   // both convergence flags and both counts are written
-        if (trace && t0 == 0 && it < 15) trace[(size_t)blockIdx.x * 32 + 1 + 2 * it] = wall_clock64();
-        const bool has1 = pb1 >= 0;
-        // ---- the exit rule
-        if (t0 == 0) {
-            const Buffers bf = phase_view(slot, xu_io, x_s_in, ref_in);
-            const bool all_conv = bf.converged[pb0] != 0 && (!has1 || bf.converged[pb1] != 0);
-            __threadfence();                                                        // this workgroup's num_solved atomics before its arrival
-            __hip_atomic_fetch_add(&bf.pcg_done[it], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-            int ex = 0;
-            if (all_conv) {
-                while (__hip_atomic_load(&bf.pcg_done[it], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) __builtin_amdgcn_s_sleep(8);
-                ex = (float)__hip_atomic_load(&bf.num_solved[it], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= thresh ? 1 : 0;
-            }
-            flags[2] = ex;
-        }
-        __syncthreads();
-        const bool exit_now = flags[2] != 0;
-        const int last = it + 1 == iters ? 1 : 0;
-#pragma unroll 1
-        for (int h = 0; h < 2; h++) {
-            if (h == 0 || has1) {
-#ifndef PAIR_NO_STEP
-                if (opaque_true()) step_body<M>(phase_view(slot, xu_io, x_s_in, ref_in), fresh_s(N_), fresh_s(B_), fresh_s(h ? pb1 : pb0), fresh_v(t0), 256, dt, (int)it, exit_now, adapt_rho,
-                                                drho_init, last, nullptr, lds);
-#endif
-            }
-            __syncthreads();   // the step's LDS (dz, merits) is free; its xu is visible to the next assembly
-        }
-        if (trace && t0 == 0 && it < 15) trace[(size_t)blockIdx.x * 32 + 2 + 2 * it] = wall_clock64();
-        if (exit_now) {
-            if (blockIdx.x == 0 && t0 == 0) phase_view(slot, xu_io, x_s_in, ref_in).ctrl->done = 1;
-            break;
-        }
-    }
-    // the last workgroup to finish sorts the trajectories by the PCG iterations this solve cost them (in eighths, 255 = 2040 and more): the
-    // pairing of the next solve on this handle (an MPC loop, a benchmark: consecutive problems are alike)
-    {
-        const Buffers bf = phase_view(slot, xu_io, x_s_in, ref_in);
-        __syncthreads();
-        if (t0 == 0) {
-            __threadfence();
-            flags[3] = __hip_atomic_fetch_add(bf.pair_fin, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (uint32_t)nW - 1 ? 1 : 0;
-        }
-        __syncthreads();
-        if (flags[3]) {
-            const int B = B_;
-            const uint32_t done = __hip_atomic_load(&bf.ctrl->iters_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            order_by(bf, B, reinterpret_cast<int*>(lds), [&](int i) {
-                int tot = 0;
-                for (uint32_t j = 0; j < done; j++) tot += __builtin_nontemporal_load(&bf.st_pcg_iters[(size_t)j * B + i]);
-                return min(tot >> 3, 255);
-            });
-        }
-    }
 }
 
 // =========================================================================================================================

@@ -225,6 +225,7 @@ class PyBSQP {
     {
         GatoMpcStep io;
         std::memset(&io, 0, sizeof(io));
+        io.struct_size = (uint32_t)sizeof(io);
         io.phases = (advance ? GATO_MPC_ADVANCE : 0) | (plan ? GATO_MPC_PLAN : 0);
         io.plant_steps = plant_steps;
         io.sim_dt = sim_dt;
@@ -314,6 +315,8 @@ PYBIND11_MODULE(GATO_EXT_NAME, m)
 {
     m.doc() = "MI355X-native batched SQP solver (pybind11 over the C ABI of libgato_hip.so); replaces python/bindings.cu";
     m.attr("version") = gato_version();
+    if (gato_abi_version() != GATO_ABI_VERSION)
+        throw std::runtime_error("libgato_hip: ABI version " + std::to_string(gato_abi_version()) + ", this module was compiled against " + std::to_string(GATO_ABI_VERSION));
     if (gato_abi_real_size() != (int)sizeof(float))   // `float` is this module's real type (see the top of the file)
         throw std::runtime_error("the library this extension is linked to carries another real type (-DGATO_DOUBLE goes with libgato_hip_f64.so)");
     // world placements (R [nq,3,3], p [nq,3], float64) of the joint frames from the library's kinematic tables -- pinocchio's

@@ -71,9 +71,6 @@ struct GatoSolver {
     int pcg_choice, pcg_fold, pcg_fused, pcg_pair;
     int cus;   // compute units of the solver's device
     int pcg_rounds;   // > 1: the PCG workgroups are scheduled hardest-first (Buffers::order), see plan_pcg
-    int persist;      // the whole SQP loop of a solve as ONE launch of sqp_pair_kernel (plan_pcg: indy7 N = 32, every pair resident; GATO_PERSIST = 0 / 1)
-    unsigned long long* d_pair_trace = nullptr;   // GATO_PAIR_TRACE: per-workgroup wall-clock stamps of sqp_pair_kernel ([wgs][32])
-    int pair_slot = -1;   // this handle's slot of g_pair_tab: the constant-memory copy of `bf` that kernel reads (xu / x_s / ref travel as kernel arguments); upload_bf
     int32_t* d_order;
     int merit_in_step_forced;   // GATO_MERIT_IN_STEP = 0 / 1, else -1
     int linear_solver;  // 0: PCG (the reference's solver, pcg.cuh), 1: direct block-tridiagonal sweep (gato_set_linear_solver)
@@ -114,6 +111,12 @@ struct GatoSolver {
     float *d_snap_xu = nullptr, *d_snap_lambda = nullptr, *d_snap_rho = nullptr;   // snapshot of what a solve changes for good: xu | lambda | rho, drho
     uint32_t* h_counts = nullptr;      // pinned: the reduced count vector, read by the host for the verdict
     uint64_t n_replays = 0, n_deferred = 0;   // statistics: speculative solves run / of those replayed (gato_get_shard_stats)
+    // after a replay the next `periter_left` sharded solves count per iteration (a batch whose exit rule fires -- an MPC loop near convergence,
+    // solve_ratio < 1 -- would otherwise pay a speculative pass plus a replay on every solve); the back-off doubles while replays keep coming
+    // (8 .. 1024) and returns to 8 with the first speculative solve that stands.  The verdict comes from the all-reduced counts: every rank
+    // takes the same decisions, so the ranks never disagree on which collectives a solve issues
+    uint32_t periter_left = 0, replay_backoff = 8;
+    uint32_t* d_agree = nullptr;       // [2]: the cross-rank agreement on the count mode (gato_comm_init / gato_set_solved_count_mode)
     size_t plant_cap;
     uint32_t max_iters_alloc;
     Buffers bf;
@@ -161,20 +164,6 @@ extern "C" int gato_dims(int plant, int N, int* nq, int* nx, int* nu, int* traj)
 
 static int plan_pcg_dispatch(GatoSolver* s);
 static int sync_last(GatoSolver* s);
-// The constant-memory copy of the buffer table (kernels.hpp: g_pair_tab) follows every change of a persistent pointer in it (creation, the
-// solved-count split of a sharded batch).  One slot per handle, PAIR_SLOTS per process; a handle that gets none keeps the launched loop.
-static bool g_slot_used[PAIR_SLOTS];
-static int upload_bf(GatoSolver* s)
-{
-    if (s->pair_slot < 0) {
-        for (int i = 0; i < PAIR_SLOTS && s->pair_slot < 0; i++)
-            if (!__atomic_test_and_set(&g_slot_used[i], __ATOMIC_ACQ_REL)) s->pair_slot = i;
-        if (s->pair_slot < 0) return GATO_OK;   // no slot: plan_pcg leaves `persist` off
-    }
-    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_pair_tab), &s->bf, sizeof(Buffers), (size_t)s->pair_slot * sizeof(Buffers), hipMemcpyHostToDevice));
-    return GATO_OK;
-}
-
 static int create_impl(GatoSolver* s, int plant, int N, int B, const GatoParams* params)
 {
     s->plant = plant; s->N = N; s->B = B;
@@ -221,9 +210,7 @@ static int create_impl(GatoSolver* s, int plant, int N, int B, const GatoParams*
         auto up = [](size_t n) { return (n + 63) & ~(size_t)63; };  // 256-byte granules, in 4-byte words
         const size_t o_dz = 0, o_pi = up((size_t)B * s->traj), o_cv = o_pi + up(B), o_ct = o_cv + up(B), o_ns = o_ct + up(sizeof(Ctrl) / 4);
         const size_t o_nsl = o_ns + up(s->max_iters_alloc);   // this rank's own solved counts (sharded batch)
-        const size_t o_pd = o_nsl + up(s->max_iters_alloc);   // sqp_pair_kernel: workgroups past the PCG of iteration i
-        const size_t o_pf = o_pd + up(s->max_iters_alloc);    // sqp_pair_kernel: workgroups that have finished the solve
-        s->zero_words = o_pf + up(1);
+        s->zero_words = o_nsl + up(s->max_iters_alloc);
         float* slab = nullptr;
         DA(slab, s->zero_words);
         s->zero_slab = slab;
@@ -234,8 +221,6 @@ static int create_impl(GatoSolver* s, int plant, int N, int B, const GatoParams*
         bf.num_solved = reinterpret_cast<uint32_t*>(slab + o_ns);
         bf.num_solved_w = bf.num_solved;   // one GPU: the count the exit rule reads is the one the PCG kernels add to
         s->d_ns_local = reinterpret_cast<uint32_t*>(slab + o_nsl);
-        bf.pcg_done = reinterpret_cast<uint32_t*>(slab + o_pd);
-        bf.pair_fin = reinterpret_cast<uint32_t*>(slab + o_pf);
     }
     DA(bf.merit, (size_t)B * NUM_ALPHAS); DA(bf.merit_cur, B); DA(bf.step, B); DA(s->d_order, B);
     DA(bf.st_pcg_iters, (size_t)s->max_iters_alloc * B); DA(bf.st_min_merit, (size_t)s->max_iters_alloc * B);
@@ -281,8 +266,6 @@ static int create_impl(GatoSolver* s, int plant, int N, int B, const GatoParams*
         HIPCHK(hipMemcpy(s->d_costw, w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice));
     }
     HIPCHK(hipDeviceSynchronize());
-    int rc_b = upload_bf(s);
-    if (rc_b != GATO_OK) return rc_b;
     return plan_pcg_dispatch(s);
 }
 
@@ -316,7 +299,6 @@ extern "C" int gato_destroy(GatoSolver* s)
     if (s->d_ee_out) (void)hipFree(s->d_ee_out);
     if (s->d_plant) (void)hipFree(s->d_plant);
     if (s->graph_exec) (void)hipGraphExecDestroy(s->graph_exec);
-    if (s->pair_slot >= 0) __atomic_clear(&g_slot_used[s->pair_slot], __ATOMIC_RELEASE);
     if (s->h_counts) (void)hipHostFree(s->h_counts);
     if (s->h_mpc_in) (void)hipHostFree(s->h_mpc_in);
     if (s->h_mpc_out) (void)hipHostFree(s->h_mpc_out);
@@ -512,26 +494,6 @@ template<class M> static int plan_pcg(GatoSolver* s)
         const char* oe = getenv("GATO_PCG_ORDER");
         const bool can = step_fused(s) && (choice == 1 || choice == 2 || choice == 3 || choice == 4);
         s->pcg_rounds = can && (oe ? atoi(oe) != 0 : s->B > s->cus) ? 2 : 1;
-    }
-    // The whole loop in one persistent launch (sqp_pair_kernel): two trajectories per 4-wavefront workgroup at 2 wavefronts per SIMD, every
-    // workgroup resident at once (a workgroup whose trajectories are all converged spins on the others' arrival).  Whether a given solve may
-    // use it (unsharded, PCG, solve_ratio >= 1, no per-stage profiling) is decided per solve: persist_ok.
-    s->persist = 0;
-    if constexpr (NX == 12) {
-        const char* pe = getenv("GATO_PERSIST");
-        const size_t lds = 2 * pcg_fused_lds<M>(s);
-        const long wgs = ((long)s->B + 1) / 2;
-        const bool can = s->pair_slot >= 0 && fused && s->N == 32 && step_fused(s) && wgs <= (long)s->cus * 2 && kkt_tasks<M>() == 4 &&
-                         grant_lds(reinterpret_cast<const void*>(&sqp_pair_kernel<M>), lds);
-        // OPT-IN (GATO_PERSIST=1): measured at C2 it is not faster than the launched loop (1.74 against 1.72 ms per solve; B = 512: 1.65 against
-        // 1.42 ms, where the launched loop runs the pair form): the median workgroup finishes after 1.38 ms, but the solve lasts as long as the
-        // workgroup that holds the hardest trajectory -- 1015 PCG iterations at ~1.0 us plus ten times (assembly + prologue + two steps) at the
-        // rates of a busy chip = 1.8 ms (wall-clock stamps per workgroup: tools/pair_trace.py, profiles/r04_pair_trace.txt)
-        s->persist = can && pe && atoi(pe) != 0 ? 1 : 0;
-        if (s->persist && getenv("GATO_PAIR_TRACE") && !s->d_pair_trace) {
-            const int rc = dalloc(s, &s->d_pair_trace, (size_t)wgs * 32);
-            if (rc != GATO_OK) return rc;
-        }
     }
     return GATO_OK;
 }
@@ -814,9 +776,29 @@ static void set_sharded(GatoSolver* s, long global_batch)
     drop_graph(s);
     s->global_batch = global_batch;
     s->bf.num_solved_w = global_batch > 0 ? s->d_ns_local : s->bf.num_solved;
-    (void)upload_bf(s);   // callers have synchronised the solver's stream (sync_last)
 }
 
+// Every rank of a communicator must count the same way (a rank in the deferred mode issues ONE reduction per solve, a rank in the per-iteration
+// mode one per SQP iteration: mixed, the collectives never match and the job hangs).  max over the ranks of {mode, 1 - mode}: both 1 = disagreement.
+static int agree_on_count_mode(GatoSolver* s)
+{
+    if (!s->comm) return GATO_OK;
+    if (!s->d_agree) {
+        int rc = dalloc(s, &s->d_agree, 2);
+        if (rc != GATO_OK) return rc;
+    }
+    const uint32_t mine[2] = {(uint32_t)(s->deferred_count ? 1 : 0), (uint32_t)(s->deferred_count ? 0 : 1)};
+    uint32_t all[2] = {0, 0};
+    hipStream_t st = s->own_stream;
+    HIPCHK(hipMemcpyAsync(s->d_agree, mine, sizeof(mine), hipMemcpyHostToDevice, st));
+    NCCLCHK(g_rccl.AllReduce(s->d_agree, s->d_agree, 2, ncclUint32, ncclMax, (ncclComm_t)s->comm, st));
+    HIPCHK(hipMemcpyAsync(all, s->d_agree, sizeof(all), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (all[0] && all[1]) return fail(GATO_ERR_INVALID, "the ranks of this communicator disagree on the solved-count mode (GATO_SOLVED_COUNT / gato_set_solved_count_mode): set the same mode on every rank");
+    return GATO_OK;
+}
+// librccl can be opened and has every entry point this library binds -- no RCCL call is made (gato_comm_unique_id would start a bootstrap listener)
+extern "C" int gato_comm_available(void) { return rccl_load(); }
 extern "C" int gato_comm_unique_id(char* out128)
 {
     if (!out128) return fail(GATO_ERR_INVALID, "null argument");
@@ -847,6 +829,13 @@ extern "C" int gato_comm_init(GatoSolver* s, const char* id128, int world_size, 
     s->world = world_size;
     s->rank = rank;
     set_sharded(s, (long)global_batch);
+    s->periter_left = 0;
+    s->replay_backoff = 8;
+    rc = agree_on_count_mode(s);
+    if (rc != GATO_OK) {   // every rank sees the same verdict: all of them drop the communicator
+        (void)gato_comm_destroy(s);
+        return fail(GATO_ERR_INVALID, "the ranks disagree on the solved-count mode (GATO_SOLVED_COUNT / gato_set_solved_count_mode before gato_comm_init): no communicator");
+    }
     return GATO_OK;
 }
 extern "C" int gato_comm_destroy(GatoSolver* s)
@@ -959,27 +948,6 @@ template<class M> static int enqueue_solve(GatoSolver* s, float dt, hipStream_t 
     return GATO_OK;
 }
 
-// ---- the persistent form: one memset + ONE launch per solve (kernels.hpp: sqp_pair_kernel) -------------------------------------------------
-static bool persist_ok(const GatoSolver* s, uint32_t iters)
-{
-    // the exit rule's fast path needs "the rule fires only when every trajectory is converged": threshold >= batch
-    return s->persist && iters > 0 && s->linear_solver == 0 && !s->profiling && s->global_batch == 0 && exit_threshold_exact(s) >= (float)s->B;
-}
-template<class M> static int enqueue_persistent(GatoSolver* s, float dt, hipStream_t st, uint32_t iters)
-{
-    constexpr int NX = 2 * M::NQ;
-    if constexpr (NX == 12) {
-        HIPCHK(hipMemsetAsync(s->zero_slab, 0, s->zero_words * sizeof(float), st));   // dz, PCG counts, convergence flags, loop control, counters
-        const int wgs = (s->B + 1) / 2;
-        hipLaunchKernelGGL((sqp_pair_kernel<M>), dim3(wgs), dim3(256), 2 * pcg_fused_lds<M>(s), st, s->pair_slot, s->bf.xu, s->bf.x_s, s->bf.ref, s->N, s->B, dt, iters,
-                           s->p.max_pcg_iters, exit_threshold_exact(s), s->adapt_rho, (const float*)s->d_drho_init, s->d_merit_init0, s->d_pair_trace);
-        HIPCHK(hipGetLastError());
-        return GATO_OK;
-    } else {
-        return fail(GATO_ERR_INVALID, "the persistent loop exists for nx = 12");
-    }
-}
-
 // async_only: the caller cannot take a host synchronisation inside the solve (stream capture): a sharded solve then shares the count per iteration
 template<class M> static int solve_impl(GatoSolver* s, float* d_xu, float dt, const float* d_xs, const float* d_ref, hipStream_t st, bool async_only = false)
 {
@@ -990,18 +958,29 @@ template<class M> static int solve_impl(GatoSolver* s, float* d_xu, float dt, co
     s->last_stream_valid = true;
     const uint32_t iters = s->p.max_sqp_iters <= s->max_iters_alloc ? s->p.max_sqp_iters : s->max_iters_alloc;
     const bool sharded = s->global_batch > 0;
-    if (!sharded && persist_ok(s, iters)) return enqueue_persistent<M>(s, dt, st, iters);
     if (!sharded) return enqueue_solve<M>(s, dt, st, iters, false);
-    if (!s->deferred_count || async_only || iters == 0) return enqueue_solve<M>(s, dt, st, iters, true);
+    bool deferred = s->deferred_count && !async_only && iters > 0;
+    if (deferred) {
+        // a caller's stream capture (gato_solve_device under hipStreamBeginCapture) cannot take the host wait of the deferred form: it would
+        // invalidate the capture.  Such a solve shares the count per iteration, the fully asynchronous form
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); deferred = false; }
+    }
+    if (deferred && s->periter_left > 0) { s->periter_left--; deferred = false; }
+    if (!deferred) return enqueue_solve<M>(s, dt, st, iters, true);
     // ---- deferred: the solved count is the ONLY coupling between the shards (bsqp.cuh:165) and on every workload where trajectories do not
     // converge it never changes anything -- ten small-message all-reduces on the critical path of every solve for nothing.  So: snapshot what a
     // solve changes for good, run it as if the rule never fired (own rows counted), reduce the whole count vector ONCE, let the host look at it.
-    if (!s->d_snap_xu) {
+    {   // each of the four is allocated once; a failure leaves the others for the next attempt and this solve returns the error
         int rc;
-        if ((rc = dalloc(s, &s->d_snap_xu, (size_t)B * s->traj, false)) != GATO_OK) return rc;
-        if ((rc = dalloc(s, &s->d_snap_lambda, (size_t)B * s->vecp, false)) != GATO_OK) return rc;
-        if ((rc = dalloc(s, &s->d_snap_rho, 2 * (size_t)B, false)) != GATO_OK) return rc;
-        HIPCHK(hipHostMalloc((void**)&s->h_counts, s->max_iters_alloc * sizeof(uint32_t), hipHostMallocDefault));
+        if (!s->d_snap_xu && (rc = dalloc(s, &s->d_snap_xu, (size_t)B * s->traj, false)) != GATO_OK) return rc;
+        if (!s->d_snap_lambda && (rc = dalloc(s, &s->d_snap_lambda, (size_t)B * s->vecp, false)) != GATO_OK) return rc;
+        if (!s->d_snap_rho && (rc = dalloc(s, &s->d_snap_rho, 2 * (size_t)B, false)) != GATO_OK) return rc;
+        if (!s->h_counts) {
+            void* hc = nullptr;
+            HIPCHK(hipHostMalloc(&hc, s->max_iters_alloc * sizeof(uint32_t), hipHostMallocDefault));
+            s->h_counts = static_cast<uint32_t*>(hc);
+        }
     }
     const size_t bx = (size_t)B * s->traj * sizeof(float), bl = (size_t)B * s->vecp * sizeof(float), bb = (size_t)B * sizeof(float);
     hipLaunchKernelGGL(snapshot_kernel, dim3(s->cus > 0 ? s->cus * 4 : 256), dim3(256), 0, st, s->d_snap_xu, (const float*)d_xu, (uint32_t)(bx / sizeof(float)),
@@ -1018,9 +997,11 @@ template<class M> static int solve_impl(GatoSolver* s, float* d_xu, float dt, co
     const float thresh = exit_threshold_exact(s);
     bool fired = false;
     for (uint32_t i = 0; i < iters; i++) fired = fired || (float)s->h_counts[i] >= thresh;
-    if (!fired) return GATO_OK;
+    if (!fired) { s->replay_backoff = 8; return GATO_OK; }
     // some iteration's whole-batch count reached the threshold: the speculative run went past the exit.  Back to the snapshot and again, exactly.
     s->n_replays++;
+    s->periter_left = s->replay_backoff;
+    s->replay_backoff = s->replay_backoff < 1024 ? s->replay_backoff * 2 : 1024;
     HIPCHK(hipMemcpyAsync(d_xu, s->d_snap_xu, bx, hipMemcpyDeviceToDevice, st));
     HIPCHK(hipMemcpyAsync(bf.lambda, s->d_snap_lambda, bl, hipMemcpyDeviceToDevice, st));
     HIPCHK(hipMemcpyAsync(bf.rho, s->d_snap_rho, bb, hipMemcpyDeviceToDevice, st));
@@ -1259,8 +1240,13 @@ extern "C" int gato_set_solved_count_mode(GatoSolver* s, int mode)
 {
     if (!s) return fail(GATO_ERR_INVALID, "null solver");
     if (mode != GATO_COUNT_DEFERRED && mode != GATO_COUNT_PER_ITERATION) return fail(GATO_ERR_INVALID, "unknown solved-count mode (0 = per iteration, 1 = deferred)");
+    GUARD(s);
+    int rc = sync_last(s);
+    if (rc) return rc;
     s->deferred_count = mode == GATO_COUNT_DEFERRED ? 1 : 0;
-    return GATO_OK;
+    s->periter_left = 0;
+    s->replay_backoff = 8;
+    return agree_on_count_mode(s);   // with a communicator this call is COLLECTIVE: every rank makes it, with the same mode
 }
 extern "C" int gato_get_shard_stats(GatoSolver* s, uint64_t* deferred_solves, uint64_t* replays)
 {
@@ -1585,6 +1571,7 @@ template<class M> static int mpc_step_impl(GatoSolver* s, GatoMpcStep* io)
 extern "C" int gato_mpc_step(GatoSolver* s, GatoMpcStep* io)
 {
     if (!s || !io) return fail(GATO_ERR_INVALID, "null argument");
+    if (io->struct_size != sizeof(GatoMpcStep)) return fail(GATO_ERR_INVALID, "GatoMpcStep::struct_size is not sizeof(GatoMpcStep) of this library: the client was compiled against another gato_abi.h");
     if (!s->mpc_begun) return fail(GATO_ERR_INVALID, "gato_mpc_begin has not been called on this solver");
     if (!(io->phases & (GATO_MPC_ADVANCE | GATO_MPC_PLAN))) return fail(GATO_ERR_INVALID, "phases: GATO_MPC_ADVANCE and / or GATO_MPC_PLAN");
     if (io->plant_steps < 0) return fail(GATO_ERR_INVALID, "plant_steps must not be negative");
@@ -1653,18 +1640,6 @@ extern "C" int gato_debug_read(GatoSolver* s, const char* name, float* out, uint
     GUARD(s);
     uint64_t l = 0;
     float* p = find_buf(s, name, &l);
-    if (!p && !strcmp(name, "pair_trace")) {   // microseconds since the earliest start stamp (wall_clock64 ticks at 100 MHz), 0 where nothing was stamped
-        const size_t n = s->d_pair_trace ? (size_t)((s->B + 1) / 2) * 32 : 0;
-        if (len) *len = n;
-        if (!out || !n) return GATO_OK;
-        std::vector<unsigned long long> t(n);
-        HIPCHK(hipDeviceSynchronize());
-        HIPCHK(hipMemcpy(t.data(), s->d_pair_trace, n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-        unsigned long long t0 = ~0ull;
-        for (size_t i = 0; i < n; i += 32) if (t[i] && t[i] < t0) t0 = t[i];
-        for (size_t i = 0; i < n && i < count; i++) out[i] = t[i] ? (float)((double)(t[i] - t0) / 100.0) : (float)0;
-        return GATO_OK;
-    }
     if (!p) {
         if (!strcmp(name, "pcg_iters") || !strcmp(name, "converged") || !strcmp(name, "order")) {  // integer buffers, returned as floats
             std::vector<int32_t> t(s->B);
@@ -1787,6 +1762,7 @@ extern "C" int gato_get_stage_times_us(GatoSolver* s, double* out7)
 
 extern "C" const char* gato_last_error(void) { return g_err.c_str(); }
 extern "C" const char* gato_version(void) { return "gato_amd 0.1.0 (gfx950)"; }
+extern "C" int gato_abi_version(void) { return GATO_ABI_VERSION; }
 extern "C" int gato_abi_real_size(void) { return (int)sizeof(float); }   // `float` is the real type here (real.hpp)
 static_assert(sizeof(GatoParams) == (kDouble ? 15 * 8 : 15 * 4), "GatoParams: 13 reals + 2 uint32 (padded to reals in the float64 build)");
 static_assert(sizeof(((GatoMpcStep*)nullptr)->x) == 16 * sizeof(float), "GatoMpcStep carries the library's real type");

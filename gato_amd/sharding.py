@@ -39,11 +39,14 @@ def connect(solver, group=None):
     the sharded batch.  The 128-byte id travels through torch.distributed (any backend); everything after that is RCCL inside the library."""
     import torch.distributed as dist
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    # 1. agree that EVERY rank can open RCCL before any rank enters a collective of its own: creating an id proves librccl.so loads and
-    #    answers.  A rank that fails here must not leave the others blocked in the broadcast or inside ncclCommInitRank.
+    # 1. agree that EVERY rank can open RCCL before any rank enters a collective of its own: gato_comm_available proves librccl.so loads and
+    #    has the entry points, without calling into it (ncclGetUniqueId would start a bootstrap listener on every rank; only rank 0 needs one).
+    #    A rank that fails here must not leave the others blocked in the broadcast or inside ncclCommInitRank.
     uid, err = None, None
     try:
-        uid = solver.comm_unique_id()
+        err = solver.comm_available()
+        if err is None and rank == 0:
+            uid = solver.comm_unique_id()
     except Exception as e:   # noqa: BLE001
         err = "%s: %s" % (type(e).__name__, e)
     flags = [None] * world
@@ -83,8 +86,20 @@ class PackedResults:
             if solver is not None:
                 solver.gather_results(self.local.data_ptr(), self.gathered.data_ptr(), self.n, stream)
             else:
+                import torch
                 import torch.distributed as dist
-                dist.all_gather_into_tensor(self.gathered, self.local, group=group)
+                if self.local.is_cuda and dist.get_backend(group) == "gloo":
+                    # device buffers, host collective (no RCCL between the ranks: two ranks sharing one GPU, or a node whose RCCL does not load):
+                    # staged through pinned host memory, ordered after the solve on torch's current stream
+                    if getattr(self, "_h_local", None) is None:
+                        self._h_local = torch.empty(self.n, dtype=self.local.dtype, pin_memory=True)
+                        self._h_all = torch.empty(self.world * self.n, dtype=self.local.dtype, pin_memory=True)
+                    self._h_local.copy_(self.local, non_blocking=True)
+                    torch.cuda.current_stream().synchronize()
+                    dist.all_gather_into_tensor(self._h_all, self._h_local, group=group)
+                    self.gathered.copy_(self._h_all, non_blocking=True)
+                else:
+                    dist.all_gather_into_tensor(self.gathered, self.local, group=group)
         return self.gathered
 
     def global_xu(self):     # [world*B, TRAJ]

@@ -173,6 +173,7 @@ class BSQP {
     void init(int plant, int knot_points, const GatoParams& p)
     {
         // the library linked must carry this translation unit's real type (libgato_hip.so: float, libgato_hip_f64.so with -DGATO_DOUBLE: double)
+        if (gato_abi_version() != GATO_ABI_VERSION) throw std::runtime_error("libgato_hip: the linked library has another ABI version than this header");
         if (gato_abi_real_size() != (int)sizeof(T)) throw std::runtime_error("libgato_hip: the linked library's real type is not sizeof(T) -- -DGATO_DOUBLE goes with libgato_hip_f64.so");
         chk(gato_create(plant, knot_points, (int)BatchSize, &p, &s_));
     }

@@ -152,6 +152,8 @@ int gato_select_best_device(GatoSolver* s, const gato_real* d_x_last, const gato
 #define GATO_MPC_ADVANCE 1 /* the plant: `plant_steps` RK4 steps of size sim_dt from the session's state */
 #define GATO_MPC_PLAN 2    /* prepare + reset_rho + solve + selection + take the best row */
 typedef struct GatoMpcStep {
+    uint32_t struct_size;    /* in: sizeof(GatoMpcStep) as the CLIENT was compiled; the library refuses any other value (a header that gained a field
+                              * must not make the library write past an older client's struct) */
     /* in */
     int32_t phases;          /* GATO_MPC_ADVANCE | GATO_MPC_PLAN (a goal-driven loop decides between the two; figure-8 tracking does both at once) */
     int32_t plant_steps;     /* RK4 steps of the plant (mpc_controller.py:199-218: int(interval / sim_dt), + 1 when the remainders add up) */
@@ -209,7 +211,10 @@ int gato_ee_pos(GatoSolver* s, const gato_real* q, int n, gato_real* out);
  * RCCL is opened with dlopen here, never linked: a single-GPU host does not need it.
  *   gato_comm_unique_id   ncclGetUniqueId: 128 bytes rank 0 hands to the others (any transport)
  *   gato_comm_init        ncclCommInitRank on the solver's device; collective over all ranks; global_batch = world_size x B
- *   gato_gather_results   ncclAllGather of `count` reals per rank on `stream`: the one data-path collective of a solve (packed iterates + merits) */
+ *   gato_gather_results   ncclAllGather of `count` reals per rank on `stream`: the one data-path collective of a solve (packed iterates + merits)
+ *   gato_comm_available   0 when librccl can be opened and has every entry point used here; no RCCL call is made (a side-effect-free probe: every
+ *                         rank calls it before ANY rank enters gato_comm_init, so that the ranks fail together or not at all) */
+int gato_comm_available(void);
 int gato_comm_unique_id(char* out128);
 int gato_comm_init(GatoSolver* s, const char* id128, int world_size, int rank, int64_t global_batch);
 int gato_comm_destroy(GatoSolver* s);
@@ -222,6 +227,11 @@ int gato_gather_results(GatoSolver* s, const gato_real* d_local, gato_real* d_al
  *       per-iteration reduction: the results are those of the unsharded solver either way, bit for bit.
  *   GATO_COUNT_PER_ITERATION        one 4-byte all-reduce between the PCG launch and the step launch of every SQP iteration, no host wait
  *       (round 3's form; also what a hipGraph capture of a sharded solve uses).
+ * A solve on a stream that is being CAPTURED (gato_solve_device under hipStreamBeginCapture) always counts per iteration: the deferred form's
+ * host wait would invalidate the capture.  After a replay the next 8 sharded solves count per iteration (doubling up to 1024 while replays keep
+ * coming): a batch whose exit rule fires on every solve pays the speculative pass once in a while, not every time.
+ * Every rank of a communicator must be in the same mode: gato_comm_init checks it (and fails on every rank alike), and with a communicator
+ * gato_set_solved_count_mode is COLLECTIVE -- every rank calls it, with the same mode.
  * gato_get_shard_stats: speculative solves run so far, and how many of them had to be replayed. */
 #define GATO_COUNT_PER_ITERATION 0
 #define GATO_COUNT_DEFERRED 1
@@ -248,6 +258,10 @@ int gato_get_stage_times_us(GatoSolver* s, double* out7);
 
 const char* gato_last_error(void);
 const char* gato_version(void);
+/* Bumped whenever a struct or an entry point of this header changes shape; every binding compares it with the GATO_ABI_VERSION it was written
+ * against at load time (include/bsqp.hpp, gato_amd/csrc/pyext.cpp, gato_amd/_lib.py) and refuses a library of another version. */
+#define GATO_ABI_VERSION 5
+int gato_abi_version(void);
 /* sizeof(gato_real) of the LIBRARY: 4 for libgato_hip.so, 8 for libgato_hip_f64.so (a client compiled with the other setting must not call it further) */
 int gato_abi_real_size(void);
 

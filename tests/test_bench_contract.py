@@ -62,3 +62,63 @@ def test_json_line(extra, workload):
     assert d.get("solution_ok") is True
     ps = d["parity_sample"]
     assert ps["rows"] >= 8 and ps["rows_on_the_oracles_step_or_a_tie"] >= ps["rows_required"] and ps["initial_merit_rel_err"] < 1e-5
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra,count_mode", [((), "deferred"), ((), "periter"),
+                                              (("--workload", "hparam", "--plant", "iiwa14", "--knots", "16", "--batch", "64"), "deferred")],
+                         ids=["fig8-deferred", "fig8-periter", "hparam-deferred"])
+def test_two_rank_rehearsal_of_the_multi_gpu_branch(extra, count_mode):
+    """bench.py's `world > 1` branch, launched exactly as the driver launches it (python -m torch.distributed.run, one process per rank), on the
+    1-GPU box: --rehearse-one-device puts both ranks on cuda:0 over gloo; RCCL refuses the duplicate device inside gato_comm_init, which drives the
+    verified fallback (results through torch.distributed, the partner's solved counts handed to the library), in both count modes.  Checked: ONE
+    JSON line from rank 0, n_gpus 2, value = the two ranks' work over the max-over-ranks time, the multi_gpu block, and that rank r solved ITS rows
+    (fig-8: rows r B ...; sweep: cost tuple r)."""
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    from gato_amd.bsqp.workloads import HPARAM_COST_GRID, fig8_problem, hparam_problem
+    hparam = "hparam" in extra
+    B = 64 if hparam else 128
+    args = list(extra) if hparam else ["--batch", str(B)]
+    env = dict(os.environ, GATO_SOLVED_COUNT=count_mode, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--rehearse-one-device", *args]
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "r05_bench_rehearsal.jsonl"), "a") as f:
+            f.write(json.dumps({"cmd": " ".join(cmd[1:]), "GATO_SOLVED_COUNT": count_mode, "line": d, "stderr_tail": r.stderr[-600:]}) + "\n")
+    except OSError:
+        pass
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["warmup"] == 1 and d["scaling"] == "weak" and d["solution_ok"] is True
+    iters = d["config"]["sqp_iters_per_solve"]
+    assert iters == 10 and d["config"]["global_batch"] == 2 * B and d["config"]["batch_per_gpu"] == B
+    assert abs(d["value"] - 2 * B * iters / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]          # both ranks' work over the max-over-ranks time
+    assert "cpu_baseline" not in d                                                                    # rank 0 at N = 1 only
+    mg = d["multi_gpu"]
+    for k in ("collective", "solved_count", "solved_count_detail", "per_rank_ms", "gather_ms", "solve_ms_without_gather", "shards", "rehearsal"):
+        assert k in mg, k
+    assert "torch.distributed" in mg["collective"] and mg["solved_count"].startswith("per shard")      # the fallback RCCL's refusal leads to
+    assert 0 < mg["per_rank_ms"]["min"] <= mg["per_rank_ms"]["median"] <= mg["per_rank_ms"]["max"] <= d["ms_per_step"] * 1.5
+    assert mg["gather_ms"]["max_over_ranks"] > 0 and mg["solve_ms_without_gather"] > 0
+    assert [s_["rank"] for s_ in mg["shards"]] == [0, 1]
+    for s_ in mg["shards"]:
+        rk = s_["rank"]
+        pr = hparam_problem("iiwa14", 16, B, shard=rk) if hparam else fig8_problem("indy7", 32, B, batch_offset=rk * B)
+        assert np.allclose(s_["first_ref_xyz"], pr["ref"][0, :3], rtol=0, atol=1e-7) and abs(s_["first_q0"] - float(pr["x_s"][0, 0])) <= 1e-7
+        if hparam:
+            assert all(abs(s_["cost_tuple"][k] - v) <= 1e-6 * abs(v) for k, v in HPARAM_COST_GRID[rk].items())   # rank g = shard g = cost tuple g
+    assert mg["shards"][0]["first_ref_xyz"] != mg["shards"][1]["first_ref_xyz"]

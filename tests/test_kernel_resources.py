@@ -17,7 +17,6 @@ CSRC = os.path.join(ROOT, "gato_amd", "csrc")
 BUDGETS = {
     r"pcgc_kernelINS_5Indy7ELi3ELi256ELb1ELb1ELb0ELb1E": (256, 0, 0),      # C2's PCG: fused Schur + fold, single-lane form, every thread owns rows (N a multiple of 16)
     r"pcgc_kernelINS_5Indy7ELi3ELi256ELb1ELb1ELb0ELb0E": (256, 16, 0),     # ... its masked form (N = 4, 8): a few AGPR copies since the body became a device function (round 4), no scratch
-    r"sqp_pair_kernelINS_5Indy7E": (256, 0, 96),                          # the persistent loop (opt-in): no scratch access inside the PCG iteration (checked on the assembly: DESIGN.md 6.1)
     r"pcgc_kernelINS_5Indy7ELi3ELi256ELb1ELb1ELb1ELb[01]E": (256, 0, 0),   # pair form
     r"pcgs_kernelINS_6Iiwa14ELi512ELb1E": (256, 0, 64),                 # C3's PCG (symmetric half storage, fold)
     r"pcgc_kernelINS_6Iiwa14ELi2ELi512ELb1ELb0ELb0E": (256, 0, 0),     # C5's PCG

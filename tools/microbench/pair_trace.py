@@ -1,5 +1,5 @@
 import os, sys, numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 os.environ["GATO_PERSIST"] = "1"; os.environ["GATO_PAIR_TRACE"] = "1"
 from gato_amd._lib import NativeSolver
