@@ -58,6 +58,18 @@ def test_host_only_entry_points(lib):
     assert lib.gato_dims(7, 8, None, None, None, None) == -1
     lib.gato_version.restype = C.c_char_p
     assert b"gfx950" in lib.gato_version()
+    # the ABI version every binding checks at load time is the header's (a struct that gains a field bumps it: advisor, round 4)
+    from gato_amd import _lib
+    ver = int(re.search(r"#define GATO_ABI_VERSION (\d+)", open(HEADER).read()).group(1))
+    assert lib.gato_abi_version() == ver == _lib.ABI_VERSION
+    # GatoMpcStep carries its size; the ctypes mirror has the header's fields in the header's order
+    hdr = open(HEADER).read()
+    body = hdr[hdr.index("typedef struct GatoMpcStep {"):hdr.index("} GatoMpcStep;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = re.findall(r"\b([a-z_]+)(?:\[\d+\])?;", body)
+    assert fields[0] == "struct_size" and fields == [f[0] for f in _lib._mpc_struct(C.c_float, "X")._fields_]
+    # librccl is probed without calling into it (0 = available; the container may or may not have it, either answer is a status, not a crash)
+    assert lib.gato_comm_available() in (0, -1, -2)
 
 
 def test_create_rejects_bad_arguments(lib):

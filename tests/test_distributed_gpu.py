@@ -217,3 +217,57 @@ def test_sharded_exit_rule_against_the_unsharded_solve(ratio, mode):
         assert 2 <= ref["iters_done"] < 6
     else:
         assert ref["iters_done"] == 6 and solved[4, :H].all() and not solved[5, H:].all()   # per-shard counting would have stopped shard 0 early
+
+
+def test_replay_backs_off_to_per_iteration_counts_and_a_captured_solve_never_waits():
+    """Advisor (round 4): a batch whose exit rule fires would pay a speculative pass plus an exact replay on EVERY solve, and the deferred form's
+    host wait inside gato_solve_device breaks a caller's stream capture.  Now: after a replay the next 8 sharded solves count per iteration
+    (same bits, one pass each), and a solve enqueued on a stream that is being captured takes the per-iteration form by itself."""
+    from gato_amd._lib import NativeSolver
+    from gato_amd.bsqp.config import DEFAULT_SOLVER_PARAMS
+    from mixed_batch import mixed_problem
+    from oracle import oracle as O
+    N, kinds = 32, "EUPPEUFFFFFF"
+    B, H = len(kinds), 6
+    p = dict(DEFAULT_SOLVER_PARAMS, max_sqp_iters=6, solve_ratio=0.5, pcg_tol=1e-8, max_pcg_iters=1000)
+    ee = lambda pl, q: O.ee(pl, q)[0]  # noqa: E731
+    pr = mixed_problem("indy7", N, kinds=kinds, ee=ee)
+    one = NativeSolver("indy7", N, B, dt=0.01, **p)
+    one.set_f_ext_batch(pr["f_ext"]); one.set_cost_weights_batch(pr["w"])
+    ref = one.solve(pr["xu"], 0.01, pr["x_s"], pr["ref"])
+    solved = np.cumsum(ref["pcg_iters_all"] == 0, axis=0) > 0
+    lo, hi = 0, H
+    sh = mixed_problem("indy7", N, kinds=kinds, ee=ee, rows=(lo, hi))
+    s = NativeSolver("indy7", N, hi - lo, dt=0.01, **p)
+    s.set_f_ext_batch(sh["f_ext"]); s.set_cost_weights_batch(sh["w"])
+    s.debug_set_remote_solved(solved[:, H:].sum(axis=1).astype(np.uint32), B)
+    graph = os.environ.get("GATO_GRAPH", "0") not in ("", "0")
+    for n in range(10):
+        s.reset_dual(); s.reset_rho()
+        r = s.solve(sh["xu"], 0.01, sh["x_s"], sh["ref"])
+        np.testing.assert_array_equal(r["XU"], ref["XU"][lo:hi])
+        np.testing.assert_array_equal(r["pcg_iters_all"], ref["pcg_iters_all"][:, lo:hi])
+        if not graph:
+            # solve 0: speculative + replay; solves 1..8: per iteration (the back-off); solve 9: speculative again (+ replay, back-off now 16)
+            assert s.shard_stats() == {"deferred_solves": 1 if n < 9 else 2, "replays": 1 if n < 9 else 2}, (n, s.shard_stats())
+    # a caller's capture of gato_solve_device on a sharded handle: no host wait inside, the graph replays to the same bits
+    s2 = NativeSolver("indy7", N, hi - lo, dt=0.01, **dict(p, solve_ratio=1.0))
+    s2.set_f_ext_batch(sh["f_ext"]); s2.set_cost_weights_batch(sh["w"])
+    s2.debug_set_remote_solved(np.zeros(6, np.uint32), B)
+    eager = s2.solve(sh["xu"], 0.01, sh["x_s"], sh["ref"])
+    before = s2.shard_stats()["deferred_solves"]
+    dev = torch.device("cuda", 0)
+    xu0 = torch.from_numpy(sh["xu"]).to(dev)
+    xu, xs, rf = xu0.clone(), torch.from_numpy(sh["x_s"]).to(dev), torch.from_numpy(sh["ref"]).to(dev)
+    side = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    s2.reset_dual(); s2.reset_rho()
+    torch.cuda.synchronize()
+    with torch.cuda.graph(g, stream=side):
+        s2.reset_async(True, True, side.cuda_stream)
+        s2.solve_device(xu.data_ptr(), 0.01, xs.data_ptr(), rf.data_ptr(), side.cuda_stream)
+    assert s2.shard_stats()["deferred_solves"] == before                 # the capture took the per-iteration form
+    xu.copy_(xu0)
+    g.replay()
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(xu.cpu().numpy(), eager["XU"])

@@ -270,3 +270,22 @@ def test_session_selection_without_a_plant_step_scores_against_the_current_state
     best, err = man.select_best(x1, best_row[12:18], x1, sim_dt)
     np.testing.assert_array_equal(out["errors"], err)
     assert out["best"] == best
+
+
+@pytest.mark.gpu
+def test_mpc_step_refuses_a_struct_of_another_size():
+    """GatoMpcStep carries sizeof(GatoMpcStep) as its client was compiled (advisor, round 4: the struct gained a field and the library wrote it
+    past an older client's struct): any other size is refused before anything is read or written."""
+    import ctypes as C
+    from gato_amd._lib import GatoError, NativeSolver
+    s = NativeSolver("indy7", 8, 2, dt=0.01, max_sqp_iters=1)
+    s.mpc_begin(np.zeros(12, np.float32))
+    io = s.L._MPC()
+    io.phases = 2
+    for bad in (0, C.sizeof(io) - 8):
+        io.struct_size = bad
+        io.best = -7
+        assert s.L.gato_mpc_step(s.h, C.byref(io)) != 0 and b"struct_size" in s.L.gato_last_error()
+        assert io.best == -7
+    out = s.mpc_step(advance=False, plan=True, ref_window=np.zeros(48, np.float32))     # the binding's own size is accepted
+    assert np.all(np.isfinite(out["x"]))
