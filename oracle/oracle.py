@@ -60,15 +60,18 @@ _lib = None
 _libs = {}
 
 
-def lib(f64=False):
-    """The fp32 oracle (default) or the float64 build of the same source (sensitivity studies: tests/test_oracle_sensitivity.py)."""
-    key = bool(f64)
+def lib(f64=False, path=None):
+    """The fp32 oracle (default) or the float64 build of the same source (sensitivity studies: tests/test_oracle_sensitivity.py).
+    path: another fp32 build of the same source (build_native), loaded beside the default one (bench.py times both)."""
+    key = bool(f64) if path is None else os.path.abspath(path)
     if key not in _libs:
-        path = LIB_PATH_F64 if key else LIB_PATH
+        f64 = bool(f64) and path is None
+        if path is None:
+            path = LIB_PATH_F64 if f64 else LIB_PATH
         if not os.path.exists(path):
             build()
-        ft = C.c_double if key else C.c_float
-        PT = OrcParams64 if key else OrcParams
+        ft = C.c_double if f64 else C.c_float
+        PT = OrcParams64 if f64 else OrcParams
         L = C.CDLL(path)
         fp = C.POINTER(ft)
         L.orc_create.restype = C.c_void_p
@@ -104,7 +107,7 @@ def lib(f64=False):
         L.orc_minv.argtypes = [C.c_int, fp, fp]
         L.orc_ee.argtypes = [C.c_int, fp, fp, fp]
         L.orc_gj_inverse.argtypes = [C.c_int, fp, fp, C.c_int]
-        L._ft, L._np, L._PT = ft, (np.float64 if key else np.float32), PT
+        L._ft, L._np, L._PT = ft, (np.float64 if f64 else np.float32), PT
         _libs[key] = L
     return _libs[key]
 
@@ -123,13 +126,13 @@ class OracleSolver:
     """Mirror of the `BSQP_{B}_float` class surface (python/bindings.cu:224-237) on the CPU oracle, plus stage access."""
 
     def __init__(self, plant, N, B, dt=0.01, max_sqp_iters=5, kkt_tol=1e-4, max_pcg_iters=100, pcg_tol=1e-5, solve_ratio=1.0, mu=10.0,
-                 q_cost=1.0, qd_cost=1e-3, u_cost=1e-6, N_cost=50.0, q_lim_cost=1e-3, vel_lim_cost=0.0, ctrl_lim_cost=0.0, rho=1e-3, threads=1, f64=False):
+                 q_cost=1.0, qd_cost=1e-3, u_cost=1e-6, N_cost=50.0, q_lim_cost=1e-3, vel_lim_cost=0.0, ctrl_lim_cost=0.0, rho=1e-3, threads=1, f64=False, library=None):
         self.plant, self.N, self.B = plant, N, B
         self.nq = NQ[plant]
         self.nx, self.nu = 2 * self.nq, self.nq
         self.traj = (self.nx + self.nu) * N - self.nu
         self.max_sqp_iters = max_sqp_iters
-        self.L = lib(f64)
+        self.L = lib(f64, library)
         self.dtype = self.L._np
         self.p = self.L._PT(dt, max_sqp_iters, kkt_tol, max_pcg_iters, pcg_tol, solve_ratio, mu, q_cost, qd_cost, u_cost, N_cost, q_lim_cost,
                            vel_lim_cost, ctrl_lim_cost, rho)
