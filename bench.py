@@ -186,6 +186,9 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (the product has no CPU fallback)")
     rehearse = bool(a.rehearse_one_device) and world > 1
+    if not rehearse and local_rank >= torch.cuda.device_count():
+        raise SystemExit("rank %d wants cuda:%d but %d device(s) are visible: one process per GPU (or --rehearse-one-device to run the multi-rank "
+                         "code path on a single GPU)" % (rank, local_rank, torch.cuda.device_count()))
     dev_index = 0 if rehearse else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)

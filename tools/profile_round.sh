@@ -8,9 +8,9 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 declare -A CMD
-CMD[c2]="$ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline"
-CMD[c3]="$ROOT/bench.py --plant iiwa14 --knots 128 --batch 256 --steps 5 --warmup 2 --no-cpu-baseline"
-CMD[c5]="$ROOT/bench.py --workload hparam --plant iiwa14 --knots 64 --batch 512 --steps 5 --warmup 2 --no-cpu-baseline"
+CMD[c2]="$ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline"   # the driver's own invocation (K = 20, W = 3)
+CMD[c3]="$ROOT/bench.py --plant iiwa14 --knots 128 --batch 256 --steps 20 --warmup 3 --no-cpu-baseline"
+CMD[c5]="$ROOT/bench.py --workload hparam --plant iiwa14 --knots 64 --batch 512 --steps 20 --warmup 3 --no-cpu-baseline"
 # direct mode at a long horizon and a small batch: the cyclic-reduction kernel (the one place MFMA runs)
 CMD[cr]="$ROOT/tools/gpu_time.py --plant indy7 -N 128 -B 8 --iters 1 --reps 20 --solver direct"
 for cfg in c2 c3 c5 cr; do
