@@ -206,7 +206,7 @@ def test_free_running_iterations_every_trajectory(case, iters):
 # fp32 evaluation, violated by any indexing / sign / layout bug: those produce errors of the size of the terms, 1e5 x the bound), and the HIP path's
 # own inputs to those formulas are the tensors already compared above; P^-1 is held to the float64 oracle as arbiter: the HIP path's worst block is
 # closer to the fp32 oracle than HALF the fp32 oracle's worst block is to float64 (measured: 5x .. 40x closer).
-SHARDS = [("C4", r) for r in range(8)] + [("C5", g) for g in range(8)]
+SHARDS = [("C4", r) for r in range(8)] + [("C5", g) for g in range(8)] + [("C3", 0)]   # + the long horizon (iiwa14 N = 128, 256 rows) for completeness
 
 
 def _rows(a, b, floor=0.0):
