@@ -120,6 +120,7 @@ def _check(case, tag, plant, N, B, p, out, pcg_counts, xu_scale=1.0):
     mx_other = float(ego[use & ~eq].max()) if (use & ~eq).any() else 0.0
     _report(test=tag, case=case, plant=plant, N=N, B=B, resolved_rows=int(resolved.sum()), steps_equal_on_resolved=int(use.sum()), near_ties=ties, departures=len(departs),
             xu_vs_fp32_oracle_max=mx, xu_vs_fp32_oracle_max_rows_with_other_pcg_counts=mx_other, xu_vs_fp32_oracle_p99=p99, xu_vs_fp32_oracle_median=med,
+            rows_within_1e_4_of_the_fp32_oracle=float((ego[use] <= 1e-4).mean()) if enough else 0.0,      # the north-star's "iterate match within 1e-4 rel", row by row
             all_rows_median_dist_to_f64_hip=float(np.median(eg)), all_rows_median_dist_to_f64_oracle32=float(np.median(e32)),
             rows_on_f64_steps_hip=int((sg == s64).sum()), rows_on_f64_steps_oracle32=int((s32 == s64).sum()),
             rows_on_fp32_oracle_steps=int(same.sum()), pcg_equal_on_resolved=int((dp[resolved] == 0).sum()), pcg_within_1_on_resolved=int((dp[resolved] <= 1).sum()), pcg_max=int(max(g["pcg_iters"][0].max(), o32["pcg_iters"][0].max())))
@@ -127,6 +128,10 @@ def _check(case, tag, plant, N, B, p, out, pcg_counts, xu_scale=1.0):
     assert ties <= max(1, 0.02 * resolved.sum()), (ties, resolved.sum())
     bmx, b99, bmed = (xu_scale * v for v in XU_BOUND[plant])
     assert mx <= bmx and p99 <= b99 and med <= bmed and mx_other <= 10 * bmx, (mx, p99, med, mx_other)
+    if enough and case not in CHAOTIC:
+        # the north-star's own figure, row by row (measured: indy7 0.91-0.93 of the rows on every shard of C4, iiwa14 N = 128 0.61; the fp32 oracle is no
+        # closer to its float64 build: the next assertions)
+        assert (ego[use] <= 1e-4).mean() >= (0.88 if plant == "indy7" else 0.5), (ego[use] <= 1e-4).mean()
     if case in CHAOTIC:
         # the sweep: the fp32 oracle itself takes the float64 step on fewer than half of the rows.  Two fp32 paths agree with each other far
         # more often than either agrees with float64 (they share the arithmetic, not the summation order), and the HIP path follows float64
