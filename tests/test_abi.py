@@ -164,6 +164,6 @@ def test_the_experiment_patches_still_apply():
     import shutil
     if shutil.which("patch") is None:
         pytest.skip("no `patch` on this host")
-    for name in ("sqp_pair.patch", "pcg_phase_trace.patch", "pcgs_split.patch"):
+    for name in ("sqp_pair.patch", "pcg_phase_trace.patch", "pcgs_split.patch", "pcgs_padded_partials.patch"):
         r = subprocess.run(["patch", "-p1", "--dry-run", "--batch", "-i", os.path.join(ROOT, "tools", "microbench", name)], cwd=ROOT, capture_output=True, text=True)
         assert r.returncode == 0, (name, r.stdout[-800:])
