@@ -11,6 +11,8 @@ fp32 HIP path vs fp32 oracle: all counters, the flags and the converged-in-itera
 fp32 keeps two implementations on one branch), the first line searches of the rows that have a decision to make; rows resting at their
 optimum compare merits that differ by rounding only: there the ITERATES are compared, to 5e-5.
 float64 HIP build vs float64 oracle: EVERYTHING, every row, every iteration -- exactly / to 1e-9."""
+import os
+
 import numpy as np
 import pytest
 
@@ -129,3 +131,32 @@ def test_early_exit_leaves_the_reference_records():
     np.testing.assert_array_equal(r2["XU"], rg["XU"])
     np.testing.assert_array_equal(r2["kkt_converged"], rg["kkt_converged"])
     assert r2["iters_done"] == it == o2["iters_done"]
+
+
+def test_a_pcg_breakdown_is_carried_like_the_reference_carries_it():
+    """fp32 PCG can break down (rho or p^T A p overflow / 0 : 0 -> a non-finite alpha): the reference has no guard (pcg.cuh:96-141), its lambda of that
+    trajectory is NaN from then on, every later merit of it is NaN, every later line search compares false and rejects (line_search.cuh:39-63), and the
+    trajectory keeps the iterate it had.  Found in round 5 on indy7 N = 128 (fig-8 rows 20 and 58 with a random wrench, second SQP iteration, both in
+    the oracle and on the device): the HIP path must break down on the SAME rows, reject the same steps, and keep every returned number finite."""
+    from gato_amd._lib import NativeSolver
+    from gato_amd.bsqp.config import DEFAULT_SOLVER_PARAMS
+    from gato_amd.bsqp.workloads import fig8_problem
+    from oracle.oracle import OracleSolver
+    plant, N, B = "indy7", 128, 64
+    pr = fig8_problem(plant, N, B, f_ext_std=1.0)
+    p = dict(DEFAULT_SOLVER_PARAMS, max_sqp_iters=6)
+    nat = NativeSolver(plant, N, B, dt=0.01, **p)
+    orc = OracleSolver(plant, N, B, dt=0.01, threads=os.cpu_count() or 1, **p)
+    for s in (nat, orc):
+        s.set_f_ext_batch(pr["f_ext"])
+    rg = nat.solve(pr["xu"], 0.01, pr["x_s"], pr["ref"])
+    ro = orc.solve(pr["xu"], 0.01, pr["x_s"], pr["ref"])
+    bad_g = ~np.isfinite(nat.read("lambda").reshape(B, N + 2, nat.nx)[:, 1:N + 1]).all(axis=(1, 2))
+    bad_o = ~np.isfinite(orc.buf("lambda")[:, 1:N + 1]).all(axis=(1, 2))
+    assert bad_o.sum() >= 1, "the configuration no longer breaks down in the oracle: pick another one"
+    np.testing.assert_array_equal(bad_g, bad_o)
+    np.testing.assert_array_equal(rg["ls_step_size"][:, bad_o], ro["ls_step_size"][:, bad_o])
+    assert np.all(rg["ls_step_size"][-1, bad_o] == -1.0)                                # rejected ever since
+    for k in ("XU", "final_merit", "initial_merit", "ls_min_merit"):
+        assert np.all(np.isfinite(rg[k])), k                                             # what the caller sees stays finite: the trajectory stands still
+    np.testing.assert_array_equal(rg["pcg_iters_all"][:, bad_o] >= 200, ro["pcg_iters_all"][:, bad_o] >= 200)
