@@ -897,3 +897,30 @@ def test_reset_async_is_reset_dual_plus_reset_rho(plant, N, B):
     s.reset_dual(); s.reset_rho()
     for k, v in a.items():
         np.testing.assert_array_equal(s.read(k), v, err_msg=k)
+
+
+@pytest.mark.parametrize("plant,N,B", [("indy7", 32, 5), ("iiwa14", 16, 1), ("indy7", 4, 1)])
+def test_a_solve_without_iterations(plant, N, B):
+    """max_sqp_iters = 0 -- the empty case of BSQP::solve (bsqp.cuh:103-197): the loop does not run, the iterate is returned as it came, initial and
+    final merit are the merit of that iterate (bsqp.cuh:116-118, 180-182), no line search and no PCG record exists, drho is back at its default
+    (bsqp.cuh:189), lambda and rho are untouched.  (The smallest sizes ride along: one trajectory, four knots.)"""
+    nat, orc, pr = make(plant, N, B, 2.0, max_sqp_iters=0)
+    lam0 = nat.read("lambda").copy()
+    rg = nat.solve(pr["xu"], DT, pr["x_s"], pr["ref"])
+    ro = orc.solve(pr["xu"], DT, pr["x_s"], pr["ref"])
+    np.testing.assert_array_equal(rg["XU"], pr["xu"])
+    assert rg["iters_done"] == ro["iters_done"] == 0 and rg["ls_num_iters"] == ro["ls_num_iters"] == 0
+    assert rg["pcg_iters"].shape[0] == 0 and rg["ls_step_size"].shape[0] == 0 and rg["ls_min_merit"].shape[0] == 0
+    np.testing.assert_array_equal(rg["sqp_iters"], ro["sqp_iters"])
+    np.testing.assert_array_equal(rg["kkt_converged"], ro["kkt_converged"])
+    np.testing.assert_array_equal(rg["final_merit"], rg["initial_merit"])
+    assert relscale(rg["initial_merit"], ro["initial_merit"]) < 1e-5 and relscale(rg["final_merit"], ro["final_merit"]) < 1e-5
+    np.testing.assert_array_equal(nat.read("lambda"), lam0)
+    np.testing.assert_array_equal(nat.read("rho"), orc.buf("rho"))
+    np.testing.assert_array_equal(nat.read("drho"), orc.buf("drho"))
+    # and the handle is as good as new afterwards: a real solve on it equals a fresh handle's
+    nat2, _, _ = make(plant, N, B, 2.0, max_sqp_iters=2)
+    nat.close()
+    nat3, _, _ = make(plant, N, B, 2.0, max_sqp_iters=0)
+    nat3.solve(pr["xu"], DT, pr["x_s"], pr["ref"])
+    assert np.all(np.isfinite(nat2.solve(pr["xu"], DT, pr["x_s"], pr["ref"])["XU"]))
