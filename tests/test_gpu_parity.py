@@ -924,3 +924,19 @@ def test_a_solve_without_iterations(plant, N, B):
     nat3, _, _ = make(plant, N, B, 2.0, max_sqp_iters=0)
     nat3.solve(pr["xu"], DT, pr["x_s"], pr["ref"])
     assert np.all(np.isfinite(nat2.solve(pr["xu"], DT, pr["x_s"], pr["ref"])["XU"]))
+
+
+@pytest.mark.parametrize("plant,N,B", [("indy7", 32, 6), ("iiwa14", 64, 3), ("indy7", 128, 2), ("indy7", 256, 2)])
+def test_a_pcg_that_may_not_iterate(plant, N, B):
+    """max_pcg_iters = 0: the loop of pcg.cuh:96-141 does not run, the kernel reports 0 iterations, and 0 iterations IS the convergence flag
+    (bsqp.cuh:153-156) -- every trajectory counts as solved in the first SQP iteration, the solve_ratio rule ends the solve before any line search
+    (bsqp.cuh:165) and the iterate comes back untouched.  Through every PCG kernel shape (fused, full storage, symmetric storage, streaming)."""
+    nat, orc, pr = make(plant, N, B, 1.0, max_sqp_iters=3, max_pcg_iters=0)
+    rg = nat.solve(pr["xu"], DT, pr["x_s"], pr["ref"])
+    ro = orc.solve(pr["xu"], DT, pr["x_s"], pr["ref"])
+    assert rg["iters_done"] == ro["iters_done"] == 1 and rg["ls_num_iters"] == ro["ls_num_iters"] == 0
+    np.testing.assert_array_equal(rg["XU"], pr["xu"])
+    for k in ("sqp_iters", "kkt_converged"):
+        np.testing.assert_array_equal(rg[k], ro[k])
+    assert np.all(rg["kkt_converged"] == 1) and np.all(rg["pcg_iters_all"] == 0)
+    assert relscale(rg["final_merit"], ro["final_merit"]) < 1e-5
