@@ -16,6 +16,12 @@ value = sum over ranks of B * iterations / wall time (max over ranks).  Rank 0 p
                              uses cuda:0, torch.distributed runs on gloo, RCCL refuses the duplicate device inside gato_comm_init, so the
                              verified fallback takes over (results through torch.distributed, the other shards' solved counts handed to
                              the library as zeros) -- every line of the multi-rank path runs except RCCL's own kernels
+    --as-rank R --of G       ONE process, ONE device, but the rows of rank R of a G-rank job (fig-8: rows [R B, (R+1) B) of the global batch; the sweep:
+                             shard R): the ranks of a sharded job hold different rows, so their solves take different times and the node runs at the
+                             slowest shard's pace -- this measures each shard's pace on the 1-GPU box (tools/scaling_prediction.py runs all of them)
+    --one-rank-comm          the library's OWN communicator with world size 1 inside the timed loop: snapshot, speculative solve, ncclAllReduce of the
+                             count vector, the host wait for the verdict, ncclAllGather of the packed results on the communication stream -- the exact
+                             call sequence of a rank of an N > 1 job (RCCL's launch path, no wire), so its cost over the plain loop is measured
 For N > 1 the line also carries per_rank_ms (min / median / max of the ranks' own loop times), gather_ms (event-timed on the communication
 stream) and solve_ms_without_gather, so that an efficiency below 1 can be attributed to skew, to the collective, or to RCCL's kernels
 taking CUs from the next solve.
@@ -86,12 +92,19 @@ def pcg_flops(nq, N, pcg_iters_all, fused_schur):
 
 
 def source_hash():
-    """hash of the kernel sources this run executes; profiles/pmc_summary.json carries the one its counters were measured on"""
-    import hashlib
-    h = hashlib.sha256()
-    for f in ("gato_amd/csrc/kernels.hpp", "gato_amd/csrc/rbd.hpp", "gato_amd/csrc/solver.hip", "gato_amd/csrc/robot_models.hpp"):
-        h.update(open(os.path.join(ROOT, f), "rb").read())
-    return h.hexdigest()[:16]
+    """hash of the kernel sources in THIS tree (tools/source_hash.py); profiles/pmc_summary.json carries the one its counters were measured on, and the
+    loaded libgato_hip.so the one it was built from (library_build()): all three go onto the line"""
+    from tools.source_hash import source_hash as _h
+    return _h()
+
+
+def library_build():
+    """the source hash baked into the libgato_hip.so this process has LOADED (-DGATO_SRC_HASH in gato_amd/csrc/Makefile): a stale binary says so"""
+    import ctypes
+    from gato_amd import _lib
+    L = _lib.load()
+    L.gato_source_hash.restype = ctypes.c_char_p
+    return L.gato_source_hash().decode()
 
 
 def usable_cores():
@@ -174,7 +187,15 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=1024)
     ap.add_argument("--rehearse-one-device", action="store_true",
                     help="N > 1 ranks sharing cuda:0 over gloo: exercises the multi-rank code path on a 1-GPU box; the value is not a scaling number")
+    ap.add_argument("--as-rank", type=int, default=None, help="with --of G: solve the rows rank R of a G-rank job would hold (one process, one device)")
+    ap.add_argument("--of", type=int, default=None, dest="of_ranks")
+    ap.add_argument("--one-rank-comm", action="store_true",
+                    help="world size 1 through the library's own communicator: the sharded call sequence (deferred count, host wait, ncclAllGather) in the timed loop")
     a = ap.parse_args()
+    if (a.as_rank is None) != (a.of_ranks is None) or (a.as_rank is not None and not 0 <= a.as_rank < a.of_ranks):
+        raise SystemExit("--as-rank R --of G go together, 0 <= R < G")
+    if (a.as_rank is not None or a.one_rank_comm) and a.gpus != 1:
+        raise SystemExit("--as-rank / --one-rank-comm are single-process runs on one device (--gpus 1)")
 
     import torch
     import torch.distributed as dist
@@ -205,6 +226,7 @@ def main():
     from gato_amd.bsqp.config import DEFAULT_SOLVER_PARAMS
     from gato_amd.bsqp.workloads import fig8_problem, hparam_problem
     plant, N, B = a.plant, a.knots, a.batch
+    shard_idx = rank if a.as_rank is None else a.as_rank      # whose rows this process solves
     # the CPU baseline is timed on BOTH builds of the oracle -- the committed x86-64-v3 library and one compiled for THIS box's host (-O3
     # -march=native) -- and the faster one is reported, by name (round 4: the native build was the slower one on the driver's box)
     oracle_native = None
@@ -217,14 +239,14 @@ def main():
             oracle_native = None
     if a.workload == "hparam":
         # BASELINE config C5: rank g = shard g of the sweep (cost tuple g, per-trajectory rho, dt 0.05, mu 1, pcg_tol 1e-3)
-        def make_problem(n, shard=rank):
+        def make_problem(n, shard=shard_idx):
             return hparam_problem(plant, N, n, shard=shard)
         pr = make_problem(B)
         params, dt = dict(pr["params"], max_sqp_iters=a.sqp_iters), pr["dt"]
         what = ("hyper-parameter sweep (gato_hparam_batch.ipynb): one random goal per trajectory, shard g on rank g = cost tuple g of the grid, "
                 "per-trajectory rho 1e-8..1e1, dt 0.05, mu 1, pcg_tol 1e-3")
     else:
-        def make_problem(n, offset=rank * B):
+        def make_problem(n, offset=shard_idx * B):
             return fig8_problem(plant, N, n, batch_offset=offset)      # rank r owns rows [r*B, (r+1)*B) of the global batch
         pr = make_problem(B)
         params, dt = dict(DEFAULT_SOLVER_PARAMS, max_sqp_iters=a.sqp_iters), 0.01
@@ -266,16 +288,29 @@ def main():
                 pass
             solver.debug_set_remote_solved(np.zeros(1, np.uint32), world * B)
         collective = "ncclAllGather on the library's communicator" if native else "torch.distributed.all_gather_into_tensor"
+    one_rank = bool(a.one_rank_comm)
+    if one_rank:
+        # the library's own communicator, world size 1: every call of a rank of an N > 1 job below (no torch.distributed in this process)
+        solver.comm_init(solver.comm_unique_id(), 1, 0)
+        probe = torch.full((4,), 1.0, device=dev)
+        got = torch.zeros(4, device=dev)
+        solver.gather_results(probe.data_ptr(), got.data_ptr(), 4, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        if not torch.equal(got, probe):
+            raise SystemExit("--one-rank-comm: the one-rank ncclAllGather did not return the probe")
+        native, coupled = True, True
+        collective = "ncclAllGather on the library's communicator (ONE rank: RCCL's launch path, no wire)"
+    sharded_loop = world > 1 or one_rank
     xu0 = torch.from_numpy(pr["xu"]).to(dev)
     x_s = torch.from_numpy(pr["x_s"]).to(dev)
     ref = torch.from_numpy(pr["ref"]).to(dev)
     # two packed result buffers [B*TRAJ iterates | B merits], solved in place and gathered by ONE collective each: the gather of solve n
     # runs on a communication stream while solve n+1 iterates in the other buffer (collectives overlapped with compute on separate HIP
     # streams); a buffer is reused only after the gather that read it has completed (per-buffer events)
-    pks = [PackedResults(B, solver.traj, world, dev) for _ in range(2)]
+    pks = [PackedResults(B, solver.traj, world, dev, own_image=one_rank) for _ in range(2)]
     main = torch.cuda.current_stream()
     stream = main.cuda_stream
-    comm = torch.cuda.Stream() if world > 1 else None
+    comm = torch.cuda.Stream() if sharded_loop else None
     done = [torch.cuda.Event(), torch.cuda.Event()]
     used = [False, False]
     count = [0]
@@ -328,14 +363,18 @@ def main():
     sync()
     t = time.perf_counter() - t0
     multi = {}
-    if world > 1:
-        tt = torch.tensor([t], dtype=torch.float64, device=cdev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        t = float(tt.item())
-        own = [torch.zeros(2, dtype=torch.float64, device=cdev) for _ in range(world)]
+    if sharded_loop:
+        def over_ranks(vals, op=None):
+            """[world][len(vals)] float64: every rank's values (one process: its own)"""
+            v = torch.tensor([float(x) for x in vals], dtype=torch.float64, device=cdev)
+            if world == 1:
+                return v.cpu().numpy()[None, :]
+            rows = [torch.zeros_like(v) for _ in range(world)]
+            dist.all_gather(rows, v)
+            return torch.stack(rows).cpu().numpy()
+        t = float(over_ranks([t])[:, 0].max())
         g_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in gather_ev])) if gather_ev else 0.0
-        dist.all_gather(own, torch.tensor([1e3 * t_own / a.steps, g_ms], dtype=torch.float64, device=cdev))
-        own = torch.stack(own).cpu().numpy()
+        own = over_ranks([1e3 * t_own / a.steps, g_ms])
         # the same loop with the gather switched off (untimed for the headline): what the collective and its kernels cost the solves
         sync()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -344,21 +383,31 @@ def main():
             step(gather=False)
         e1.record(main)
         sync()
-        ng = torch.tensor([e0.elapsed_time(e1) / max(2, a.steps // 4)], dtype=torch.float64, device=cdev)
-        dist.all_reduce(ng, op=dist.ReduceOp.MAX)
-        sh = solver.shard_stats()
+        ng = float(over_ranks([e0.elapsed_time(e1) / max(2, a.steps // 4)])[:, 0].max())
+        # how the solves of this run actually learned the count, from the LIBRARY (not from the environment): speculative solves, the replays among
+        # them, and the solves that counted per iteration (the mode, or the back-off after a replay) -- summed over the ranks
+        sh, cs = solver.shard_stats(), solver.solved_count_state()
+        cnt = over_ranks([sh["deferred_solves"], sh["replays"], cs["per_iteration_solves"], 1.0 if cs["mode"] == "deferred" else 0.0])
+        modes = sorted({"deferred" if m else "per_iteration" for m in cnt[:, 3]})
         multi = {"collective": collective,
-                 "solved_count": ("deferred" if os.environ.get("GATO_SOLVED_COUNT", "") != "periter" else "per_iteration") if coupled else "per shard (no communicator)",
-                 "solved_count_detail": ("speculative solve + ONE ncclAllReduce of the per-iteration count vector per solve; %d of %d solves replayed exactly"
-                                         % (sh["replays"], sh["deferred_solves"])) if coupled else "shards count alone: exact while the whole batch's exit rule never fires (checked: solution_checks)",
+                 "solved_count": ("/".join(modes) + " (gato_get_solved_count_state)") if coupled else "per shard (no communicator)",
+                 "solved_count_detail": ("over all ranks: %d speculative solves (ONE ncclAllReduce of the per-iteration count vector each), %d of them replayed exactly, "
+                                         "%d solves with one 4-byte ncclAllReduce per SQP iteration (the mode, or the back-off after a replay)"
+                                         % (cnt[:, 0].sum(), cnt[:, 1].sum(), cnt[:, 2].sum())) if coupled
+                                        else "shards count alone: exact while the whole batch's exit rule never fires (checked: solution_checks)",
+                 "solves_by_count_form": {"speculative": int(cnt[:, 0].sum()), "replayed": int(cnt[:, 1].sum()), "per_iteration": int(cnt[:, 2].sum())},
                  "per_rank_ms": {"min": float(own[:, 0].min()), "median": float(np.median(own[:, 0])), "max": float(own[:, 0].max())},
                  "gather_ms": {"mean_over_ranks": float(own[:, 1].mean()), "max_over_ranks": float(own[:, 1].max())},
-                 "solve_ms_without_gather": float(ng.item()),
-                 "shards": [{"rank": int(r[0]), "first_ref_xyz": [float(r[1]), float(r[2]), float(r[3])], "first_q0": float(r[4]),
-                             "cost_tuple": {"q_cost": float(r[5]), "qd_cost": float(r[6]), "u_cost": float(r[7]), "N_cost": float(r[8])}} for r in shard_rows]}
+                 "solve_ms_without_gather": ng}
+        if world > 1:
+            multi["shards"] = [{"rank": int(r[0]), "first_ref_xyz": [float(r[1]), float(r[2]), float(r[3])], "first_q0": float(r[4]),
+                                "cost_tuple": {"q_cost": float(r[5]), "qd_cost": float(r[6]), "u_cost": float(r[7]), "N_cost": float(r[8])}} for r in shard_rows]
         if rehearse:
             multi["rehearsal"] = ("%d ranks sharing ONE device over gloo: a run of the multi-rank code path, not a scaling measurement "
                                   "(the solves of the ranks time-share the GPU)" % world)
+        if one_rank:
+            multi["one_rank_comm"] = ("ONE rank through the library's own communicator: snapshot + speculative solve + ncclAllReduce of the count vector + the host "
+                                      "wait for the verdict + ncclAllGather on the communication stream in every timed step (a rank's call sequence in an N > 1 job)")
 
     st = solver.stats()
     iters = st["iters_done"]
@@ -409,6 +458,19 @@ def main():
             parity = {"error": "%s: %s" % (type(e).__name__, e)}
             checks["parity_sample"] = False
             ok = False
+    if world > 1:
+        # the line carries the AND over ALL shards (a non-finite or worsened row on rank 5 must reach it), and says which ranks failed what
+        names = sorted(k for k in checks if k != "parity_sample")            # the parity sample is rank 0's alone
+        fl = torch.tensor([1.0 if checks[k] else 0.0 for k in names], dtype=torch.float64, device=cdev)
+        rows = [torch.zeros_like(fl) for _ in range(world)]
+        dist.all_gather(rows, fl)
+        rows = torch.stack(rows).cpu().numpy()
+        failed = {k: [int(r) for r in np.nonzero(rows[:, i] == 0)[0]] for i, k in enumerate(names) if (rows[:, i] == 0).any()}
+        for i, k in enumerate(names):
+            checks[k] = bool(rows[:, i].all())
+        if failed:
+            checks["failed_on_ranks"] = failed
+        ok = all(v for k, v in checks.items() if k != "failed_on_ranks")
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -431,6 +493,10 @@ def main():
     # both roofs of the dominant kernel (the PCG launch): HBM from the algorithmic bytes, fp32 VALU from the flops the device's own
     # iteration counts imply; `bound` is the larger fraction.  The launch is latency-shaped: both are small.
     hbm_frac = achieved / HBM_PEAK_GBS
+    # the binary that ran vs the sources of this tree: the library carries the hash of what it was built from (gato_source_hash); a stale .so fails the line
+    lib_build = library_build()
+    checks["library_built_from_this_tree"] = bool(lib_build == source_hash())
+    ok = ok and checks["library_built_from_this_tree"]
     valu = None
     if dom == "pcg":
         fl = pcg_flops(NativeSolver_nq(plant), N, st["pcg_iters_all"], fused_schur)
@@ -448,7 +514,8 @@ def main():
             if rows:
                 k, v = max(rows, key=lambda kv: kv[1].get("pct_of_gpu_time", 0.0))
                 traffic = v.get("hbm_bytes")
-                pmc = {"section": section, "kernel": k, "profiled_build": js.get("build"), "this_build": source_hash(), "build_matches": js.get("build") == source_hash(),
+                pmc = {"section": section, "kernel": k, "profiled_build": js.get("build"), "this_build": source_hash(), "library_build": lib_build,
+                       "build_matches": js.get("build") == source_hash() == lib_build,
                        "rocprof_avg_us": v.get("avg_us"), "valu_issue_frac": v.get("valu_issue_frac"), "lds_bank_conflict_frac": v.get("lds_bank_conflict_frac"),
                        "mfma_busy_cycles": v.get("mfma_busy_cycles")}
         except Exception:
@@ -456,16 +523,22 @@ def main():
     hbm = {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_frac, "algorithmic_bytes_per_launch": dom_bytes}
     top = valu if (valu and valu["frac"] >= hbm_frac) else hbm
     line = {
-        "metric": "SQP iterations/sec (whole node), indy7 N=32 batch=1024, 1/2/4/8 MI355X" if (plant, N, B, a.workload) == ("indy7", 32, 1024, "fig8")
-                  else "SQP iterations/sec (whole node), %s N=%d batch=%d %s (not the headline configuration)" % (plant, N, B, a.workload),
+        "metric": ("REHEARSAL on one device (not a measurement): " if rehearse else "")
+                  + ("SQP iterations/sec (whole node), indy7 N=32 batch=1024, 1/2/4/8 MI355X" if (plant, N, B, a.workload) == ("indy7", 32, 1024, "fig8")
+                     else "SQP iterations/sec (whole node), %s N=%d batch=%d %s (not the headline configuration)" % (plant, N, B, a.workload))
+                  + (" -- the rows of rank %d of %d, solved alone on one device (scaling prediction, not the headline)" % (a.as_rank, a.of_ranks) if a.as_rank is not None else "")
+                  + (" -- through the library's one-rank communicator" if one_rank else ""),
         "value": value, "unit": "trajectory-SQP-iterations/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": 1e3 * t / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s N=%d batch=%d per GPU (global %d), %s, %d SQP iterations per solve, reset_dual+reset_rho per solve"
                                % (plant, N, B, world * B, what, iters),
                    "plant": plant, "knot_points": N, "batch_per_gpu": B, "global_batch": world * B, "sqp_iters_per_solve": int(iters),
+                   "rows_of_rank": {"rank": int(shard_idx), "of": int(a.of_ranks if a.as_rank is not None else world)},
+                   "sum_over_launches_of_max_pcg_iters": int(st["pcg_iters_all"].max(axis=1).sum()),
                    "mean_pcg_iters": float(st["pcg_iters_all"].mean()), "parallelism": ("one GPU: the whole batch in one solver handle" if world == 1 else
                                    "batch-sharded x%d (one process per GPU), the solved count of the exit rule reduced ONCE per solve behind a speculative solve "
                                    "(multi_gpu.solved_count), one packed all_gather of iterates + merits per solve, overlapped with the next solve" % world)},
+        "library": {"version": lib_version(), "built_from": lib_build, "tree": source_hash()},
         "roofline": {"bound": "valu" if top is valu else "hbm", "kernel": dom, "achieved": top["achieved"], "peak": top["peak"], "unit": top["unit"],
                      "frac": top["frac"], "traffic": traffic, "hbm": hbm, "valu": valu, "pmc": pmc, "avg_launch_us": per_launch_us[dom],
                      "stage_us_per_solve": {k: round(v, 1) for k, v in stage_acc.items()},
@@ -493,6 +566,11 @@ def main():
     print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
+
+
+def lib_version():
+    from gato_amd import _lib
+    return _lib.load().gato_version().decode()
 
 
 def NativeSolver_nq(plant):

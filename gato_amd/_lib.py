@@ -23,8 +23,9 @@ SYMBOLS = [
     "gato_mpc_begin", "gato_mpc_step", "gato_mpc_get_best", "gato_plant_payload_rk4", "gato_mpc_set_payload", "gato_mpc_get_payload",
     "gato_comm_unique_id", "gato_comm_init", "gato_comm_destroy", "gato_gather_results", "gato_debug_set_remote_solved", "gato_abi_real_size",
     "gato_set_solved_count_mode", "gato_get_shard_stats", "gato_comm_available", "gato_abi_version",
+    "gato_comm_init_rank", "gato_comm_confirm", "gato_get_solved_count_state", "gato_source_hash",
 ]
-ABI_VERSION = 5   # GATO_ABI_VERSION of the include/gato_abi.h this binding was written against
+ABI_VERSION = 6   # GATO_ABI_VERSION of the include/gato_abi.h this binding was written against
 
 
 def _params_struct(ft, name):
@@ -39,7 +40,7 @@ def _mpc_struct(ft, name):
     return type(name, (C.Structure,), {"_fields_": [
         ("struct_size", C.c_uint32), ("phases", C.c_int32), ("plant_steps", C.c_int32), ("sim_dt", ft), ("steps_per_knot", C.c_double), ("plant_wrench", ft * 6),
         ("ref_window", C.POINTER(ft)), ("hyp_world", C.POINTER(ft)), ("select", C.c_int32), ("select_dt", ft), ("x", ft * 16), ("ee", ft * 3),
-        ("best", C.c_int32), ("solve_us", C.c_double), ("errors", C.POINTER(ft)), ("plant_us", C.c_double)]})
+        ("best", C.c_int32), ("solve_us", C.c_double), ("errors", C.POINTER(ft)), ("solve_wall_us", C.c_double), ("plant_us", C.c_double)]})
 
 
 GatoParams = _params_struct(C.c_float, "GatoParams")
@@ -92,6 +93,10 @@ def load(f64=False):
     L.gato_debug_set_remote_solved.argtypes = [vp, C.POINTER(C.c_uint32), C.c_int, C.c_int64]
     L.gato_set_solved_count_mode.argtypes = [vp, C.c_int]
     L.gato_get_shard_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.gato_get_solved_count_state.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
+    L.gato_comm_init_rank.argtypes = [vp, C.c_char_p, C.c_int, C.c_int, C.c_int64]
+    L.gato_comm_confirm.argtypes = [vp]
+    L.gato_source_hash.restype = C.c_char_p
     L.gato_default_params.argtypes = [C.POINTER(PT)]
     L.gato_default_params.restype = None
     L.gato_dims.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
@@ -351,10 +356,10 @@ class NativeSolver:
         self._chk(self.L.gato_mpc_begin(self.h, self._p(self._f(x0, (self.nx,)))))
 
     def mpc_step(self, advance=True, plan=True, plant_steps=0, sim_dt=0.001, steps_per_knot=1.0, plant_wrench=None, ref_window=None, hyp_world=None,
-                 select=False, select_dt=0.0):
+                 select=False, select_dt=0.0, time_solve_wall=False):
         io = self.L._MPC()
         io.struct_size = C.sizeof(io)
-        io.phases = (1 if advance else 0) | (2 if plan else 0)
+        io.phases = (1 if advance else 0) | (2 if plan else 0) | (4 if time_solve_wall else 0)
         io.plant_steps, io.sim_dt, io.steps_per_knot = int(plant_steps), float(sim_dt), float(steps_per_knot)
         fw = self._f(np.zeros(6) if plant_wrench is None else plant_wrench, (6,))
         for i in range(6):
@@ -368,7 +373,7 @@ class NativeSolver:
         err = np.zeros(self.B, self.dtype)
         io.errors = self._p(err)
         self._chk(self.L.gato_mpc_step(self.h, C.byref(io)))
-        return {"x": np.array(io.x[: self.nx], self.dtype), "ee": np.array(io.ee[:3], self.dtype), "best": int(io.best), "solve_us": float(io.solve_us),
+        return {"x": np.array(io.x[: self.nx], self.dtype), "ee": np.array(io.ee[:3], self.dtype), "best": int(io.best), "solve_us": float(io.solve_us), "solve_wall_us": float(io.solve_wall_us),
                 "plant_us": float(io.plant_us), "errors": err}
 
     def mpc_best(self):
@@ -395,6 +400,14 @@ class NativeSolver:
         """collective over all ranks: this solver becomes shard `rank` of a batch of world_size x B trajectories"""
         self._chk(self.L.gato_comm_init(self.h, C.c_char_p(bytes(unique_id)), int(world_size), int(rank), int(world_size) * self.B))
 
+    def comm_init_rank(self, unique_id, world_size, rank):
+        """step 1 of comm_init: ncclCommInitRank alone -- no collective on the new communicator yet (sharding.connect compares the ranks' outcomes first)"""
+        self._chk(self.L.gato_comm_init_rank(self.h, C.c_char_p(bytes(unique_id)), int(world_size), int(rank), int(world_size) * self.B))
+
+    def comm_confirm(self):
+        """step 2, collective on the new communicator: the ranks agree on the solved-count mode; sharded solves refuse before it"""
+        self._chk(self.L.gato_comm_confirm(self.h))
+
     def comm_destroy(self):
         self._chk(self.L.gato_comm_destroy(self.h))
 
@@ -416,6 +429,13 @@ class NativeSolver:
         a, b = C.c_uint64(), C.c_uint64()
         self._chk(self.L.gato_get_shard_stats(self.h, C.byref(a), C.byref(b)))
         return {"deferred_solves": int(a.value), "replays": int(b.value)}
+
+    def solved_count_state(self):
+        """the count mode the handle is in, the sharded solves that counted per iteration so far (mode, capture, back-off after a replay) and
+        how many more the back-off will take that way"""
+        m, n, left = C.c_int(), C.c_uint64(), C.c_uint32()
+        self._chk(self.L.gato_get_solved_count_state(self.h, C.byref(m), C.byref(n), C.byref(left)))
+        return {"mode": "deferred" if m.value == 1 else "per_iteration", "per_iteration_solves": int(n.value), "per_iteration_left": int(left.value)}
 
     def synchronize(self):
         self._chk(self.L.gato_synchronize(self.h))

@@ -85,6 +85,8 @@ class MPC_GATO:
         self.nx, self.nu = self.solver.nx, self.solver.nu
         self.N, self.dt, self.batch_size, self.track_full_stats = N, dt, batch_size, track_full_stats
         self.step_wall_s = []
+        self.time_solve_wall = False   # True: every planning step also records the host wall clock around its solve alone (self.solve_wall_us; slower steps)
+        self.solve_wall_us = []
         self.setup_external_forces(constant_f_ext)
         self.setup_force_estimator()
 
@@ -171,8 +173,13 @@ class MPC_GATO:
         hyp = self._hypotheses() if plan else None
         t0 = time.perf_counter()
         out = dev.mpc_step(advance=advance, plan=plan, plant_steps=nsteps, sim_dt=sim_dt, steps_per_knot=self.dt / sim_dt, plant_wrench=self.actual_f_ext,
-                           ref_window=window, hyp_world=hyp, select=plan and hyp is not None, select_dt=max(sim_dt, round(latency / sim_dt) * sim_dt))
+                           ref_window=window, hyp_world=hyp, select=plan and hyp is not None, select_dt=max(sim_dt, round(latency / sim_dt) * sim_dt),
+                           time_solve_wall=bool(getattr(self, "time_solve_wall", False)))
         out["wall_s"] = time.perf_counter() - t0
+        if getattr(self, "time_solve_wall", False) and plan:
+            # measurement mode (tools/mpc_heatmap.py --solve-wall): the host wall clock around the solve alone, device-synchronised on both sides --
+            # the reference's own `sqp_time_us` (bsqp.cuh:109,185), which is what its published solve-time heat-map shows
+            self.solve_wall_us.append(out["solve_wall_us"])
         self.step_wall_s.append(out["wall_s"])   # host wall time of every session call (not a statistics key of the reference)
         # The CONTROLLER's latency: the reference charges the time around solver.solve only (mpc_controller.py:234-236).  Simulating the plant
         # is not controller time -- fed back as latency it adds plant steps, which add wall time (the payload plant is several times as

@@ -221,12 +221,12 @@ class PyBSQP {
         return out;
     }
     py::dict mpc_step(bool advance, bool plan, int plant_steps, float sim_dt, double steps_per_knot, py::object plant_wrench, py::object ref_window,
-                      py::object hyp_world, bool select, float select_dt)
+                      py::object hyp_world, bool select, float select_dt, bool time_solve_wall)
     {
         GatoMpcStep io;
         std::memset(&io, 0, sizeof(io));
         io.struct_size = (uint32_t)sizeof(io);
-        io.phases = (advance ? GATO_MPC_ADVANCE : 0) | (plan ? GATO_MPC_PLAN : 0);
+        io.phases = (advance ? GATO_MPC_ADVANCE : 0) | (plan ? GATO_MPC_PLAN : 0) | (time_solve_wall ? GATO_MPC_TIME_SOLVE : 0);
         io.plant_steps = plant_steps;
         io.sim_dt = sim_dt;
         io.steps_per_knot = steps_per_knot;
@@ -259,6 +259,7 @@ class PyBSQP {
         r["ee"] = ee;
         r["best"] = (int)io.best;
         r["solve_us"] = io.solve_us;
+        r["solve_wall_us"] = io.solve_wall_us;
         r["plant_us"] = io.plant_us;
         r["errors"] = err;
         return r;
@@ -361,7 +362,7 @@ PYBIND11_MODULE(GATO_EXT_NAME, m)
         .def("mpc_payload", &PyBSQP::mpc_payload)
         .def("mpc_begin", &PyBSQP::mpc_begin)
         .def("mpc_step", &PyBSQP::mpc_step, py::arg("advance"), py::arg("plan"), py::arg("plant_steps"), py::arg("sim_dt"), py::arg("steps_per_knot"),
-             py::arg("plant_wrench"), py::arg("ref_window"), py::arg("hyp_world"), py::arg("select"), py::arg("select_dt"))
+             py::arg("plant_wrench"), py::arg("ref_window"), py::arg("hyp_world"), py::arg("select"), py::arg("select_dt"), py::arg("time_solve_wall") = false)
         .def("mpc_best", &PyBSQP::mpc_best)
         .def("last_stats", &PyBSQP::last_stats)
         .def_property_readonly("knot_points", &PyBSQP::knot_points)

@@ -111,6 +111,8 @@ struct GatoSolver {
     float *d_snap_xu = nullptr, *d_snap_lambda = nullptr, *d_snap_rho = nullptr;   // snapshot of what a solve changes for good: xu | lambda | rho, drho
     uint32_t* h_counts = nullptr;      // pinned: the reduced count vector, read by the host for the verdict
     uint64_t n_replays = 0, n_deferred = 0;   // statistics: speculative solves run / of those replayed (gato_get_shard_stats)
+    uint64_t n_periter = 0;            // sharded solves that shared the count per SQP iteration instead: the mode, a capture, or the back-off after a replay
+    bool comm_confirmed = false;       // the ranks have agreed on the count mode over THIS communicator (gato_comm_confirm): sharded solves refuse before
     // after a replay the next `periter_left` sharded solves count per iteration (a batch whose exit rule fires -- an MPC loop near convergence,
     // solve_ratio < 1 -- would otherwise pay a speculative pass plus a replay on every solve); the back-off doubles while replays keep coming
     // (8 .. 1024) and returns to 8 with the first speculative solve that stands.  The verdict comes from the all-reduced counts: every rank
@@ -780,8 +782,9 @@ static void set_sharded(GatoSolver* s, long global_batch)
 
 // Every rank of a communicator must count the same way (a rank in the deferred mode issues ONE reduction per solve, a rank in the per-iteration
 // mode one per SQP iteration: mixed, the collectives never match and the job hangs).  max over the ranks of {mode, 1 - mode}: both 1 = disagreement.
-static int agree_on_count_mode(GatoSolver* s)
+static int agree_on_count_mode(GatoSolver* s, bool* disagree = nullptr)
 {
+    if (disagree) *disagree = false;
     if (!s->comm) return GATO_OK;
     if (!s->d_agree) {
         int rc = dalloc(s, &s->d_agree, 2);
@@ -794,7 +797,10 @@ static int agree_on_count_mode(GatoSolver* s)
     NCCLCHK(g_rccl.AllReduce(s->d_agree, s->d_agree, 2, ncclUint32, ncclMax, (ncclComm_t)s->comm, st));
     HIPCHK(hipMemcpyAsync(all, s->d_agree, sizeof(all), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    if (all[0] && all[1]) return fail(GATO_ERR_INVALID, "the ranks of this communicator disagree on the solved-count mode (GATO_SOLVED_COUNT / gato_set_solved_count_mode): set the same mode on every rank");
+    if (all[0] && all[1]) {
+        if (disagree) *disagree = true;
+        return fail(GATO_ERR_INVALID, "the ranks of this communicator disagree on the solved-count mode (GATO_SOLVED_COUNT / gato_set_solved_count_mode): set the same mode on every rank");
+    }
     return GATO_OK;
 }
 // librccl can be opened and has every entry point this library binds -- no RCCL call is made (gato_comm_unique_id would start a bootstrap listener)
@@ -810,7 +816,9 @@ extern "C" int gato_comm_unique_id(char* out128)
     memcpy(out128, &id, sizeof(id));
     return GATO_OK;
 }
-extern "C" int gato_comm_init(GatoSolver* s, const char* id128, int world_size, int rank, int64_t global_batch)
+// step 1 of 2: ncclCommInitRank alone.  No collective is issued on the new communicator, so a caller with a side channel (gato_amd.sharding.connect:
+// torch.distributed) can compare the ranks' return codes first and let every rank drop an initialisation that failed on ANY of them
+extern "C" int gato_comm_init_rank(GatoSolver* s, const char* id128, int world_size, int rank, int64_t global_batch)
 {
     if (!s || !id128) return fail(GATO_ERR_INVALID, "null argument");
     if (world_size < 1 || rank < 0 || rank >= world_size) return fail(GATO_ERR_INVALID, "rank must lie in [0, world_size)");
@@ -824,19 +832,41 @@ extern "C" int gato_comm_init(GatoSolver* s, const char* id128, int world_size, 
     ncclUniqueId id;
     memcpy(&id, id128, sizeof(id));
     ncclComm_t c = nullptr;
+    if (!s->d_agree && (rc = dalloc(s, &s->d_agree, 2)) != GATO_OK) return rc;   // step 2's only allocation, made HERE: what can still fail there is HIP / RCCL itself
     NCCLCHK(g_rccl.CommInitRank(&c, world_size, id, rank));
     s->comm = c;
+    s->comm_confirmed = false;
     s->world = world_size;
     s->rank = rank;
     set_sharded(s, (long)global_batch);
     s->periter_left = 0;
     s->replay_backoff = 8;
-    rc = agree_on_count_mode(s);
-    if (rc != GATO_OK) {   // every rank sees the same verdict: all of them drop the communicator
-        (void)gato_comm_destroy(s);
-        return fail(GATO_ERR_INVALID, "the ranks disagree on the solved-count mode (GATO_SOLVED_COUNT / gato_set_solved_count_mode before gato_comm_init): no communicator");
-    }
     return GATO_OK;
+}
+// step 2 of 2, COLLECTIVE on the new communicator: the ranks agree on the solved-count mode; sharded solves refuse until this has succeeded.
+// A disagreement is seen by every rank alike (the reduced pair is the same everywhere): all of them drop the communicator.  Any OTHER failure
+// (allocation, HIP, RCCL) is this rank's alone: its own message is kept, the communicator is dropped HERE, and the peers -- who may have
+// passed -- are left with a communicator whose partner is gone: they must gato_comm_destroy (sharding.connect compares the ranks' verdicts)
+extern "C" int gato_comm_confirm(GatoSolver* s)
+{
+    if (!s) return fail(GATO_ERR_INVALID, "null solver");
+    if (!s->comm) return fail(GATO_ERR_INVALID, "the solver has no communicator (gato_comm_init_rank)");
+    GUARD(s);
+    bool disagree = false;
+    const int rc = agree_on_count_mode(s, &disagree);
+    if (rc != GATO_OK) {
+        const std::string why = g_err;
+        (void)gato_comm_destroy(s);
+        return fail(rc, disagree ? "the ranks disagree on the solved-count mode (GATO_SOLVED_COUNT / gato_set_solved_count_mode before gato_comm_init): no communicator on any rank"
+                                 : "this rank failed while the ranks agreed on the solved-count mode (its communicator is dropped; the peers must gato_comm_destroy theirs): " + why);
+    }
+    s->comm_confirmed = true;
+    return GATO_OK;
+}
+extern "C" int gato_comm_init(GatoSolver* s, const char* id128, int world_size, int rank, int64_t global_batch)
+{
+    const int rc = gato_comm_init_rank(s, id128, world_size, rank, global_batch);
+    return rc != GATO_OK ? rc : gato_comm_confirm(s);
 }
 extern "C" int gato_comm_destroy(GatoSolver* s)
 {
@@ -848,6 +878,7 @@ extern "C" int gato_comm_destroy(GatoSolver* s)
     if (s->comm) {
         NCCLCHK(g_rccl.CommDestroy((ncclComm_t)s->comm));
         s->comm = nullptr;
+        s->comm_confirmed = false;
     }
     s->world = 1;
     s->rank = 0;
@@ -959,6 +990,8 @@ template<class M> static int solve_impl(GatoSolver* s, float* d_xu, float dt, co
     const uint32_t iters = s->p.max_sqp_iters <= s->max_iters_alloc ? s->p.max_sqp_iters : s->max_iters_alloc;
     const bool sharded = s->global_batch > 0;
     if (!sharded) return enqueue_solve<M>(s, dt, st, iters, false);
+    if (s->comm && !s->comm_confirmed)
+        return fail(GATO_ERR_INVALID, "the communicator is not confirmed: gato_comm_confirm (the ranks' agreement on the solved-count mode) has not succeeded on this handle");
     bool deferred = s->deferred_count && !async_only && iters > 0;
     if (deferred) {
         // a caller's stream capture (gato_solve_device under hipStreamBeginCapture) cannot take the host wait of the deferred form: it would
@@ -967,7 +1000,7 @@ template<class M> static int solve_impl(GatoSolver* s, float* d_xu, float dt, co
         if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); deferred = false; }
     }
     if (deferred && s->periter_left > 0) { s->periter_left--; deferred = false; }
-    if (!deferred) return enqueue_solve<M>(s, dt, st, iters, true);
+    if (!deferred) { s->n_periter++; return enqueue_solve<M>(s, dt, st, iters, true); }
     // ---- deferred: the solved count is the ONLY coupling between the shards (bsqp.cuh:165) and on every workload where trajectories do not
     // converge it never changes anything -- ten small-message all-reduces on the critical path of every solve for nothing.  So: snapshot what a
     // solve changes for good, run it as if the rule never fired (own rows counted), reduce the whole count vector ONCE, let the host look at it.
@@ -1006,7 +1039,7 @@ template<class M> static int solve_impl(GatoSolver* s, float* d_xu, float dt, co
     HIPCHK(hipMemcpyAsync(bf.lambda, s->d_snap_lambda, bl, hipMemcpyDeviceToDevice, st));
     HIPCHK(hipMemcpyAsync(bf.rho, s->d_snap_rho, bb, hipMemcpyDeviceToDevice, st));
     HIPCHK(hipMemcpyAsync(bf.drho, s->d_snap_rho + B, bb, hipMemcpyDeviceToDevice, st));
-    return enqueue_solve<M>(s, dt, st, iters, true);
+    return enqueue_solve<M>(s, dt, st, iters, true);   // (counted in n_replays, not in n_periter: that one counts solves that never ran speculatively)
 }
 
 static int solve_dispatch(GatoSolver* s, float* d_xu, float dt, const float* d_xs, const float* d_ref, hipStream_t st, bool async_only = false)
@@ -1243,16 +1276,30 @@ extern "C" int gato_set_solved_count_mode(GatoSolver* s, int mode)
     GUARD(s);
     int rc = sync_last(s);
     if (rc) return rc;
+    const int before = s->deferred_count;
     s->deferred_count = mode == GATO_COUNT_DEFERRED ? 1 : 0;
+    // with a communicator this call is COLLECTIVE: every rank makes it, with the same mode.  On a disagreement every rank sees the same verdict
+    // and every rank goes back to the mode it had -- which gato_comm_confirm had found equal on all of them: mixed modes (mismatched collectives:
+    // a hang in the next sharded solve) cannot be left behind.  Any other failure is this rank's alone and also restores its mode.
+    rc = agree_on_count_mode(s);
+    if (rc != GATO_OK) { s->deferred_count = before; return rc; }
     s->periter_left = 0;
     s->replay_backoff = 8;
-    return agree_on_count_mode(s);   // with a communicator this call is COLLECTIVE: every rank makes it, with the same mode
+    return GATO_OK;
 }
 extern "C" int gato_get_shard_stats(GatoSolver* s, uint64_t* deferred_solves, uint64_t* replays)
 {
     if (!s) return fail(GATO_ERR_INVALID, "null solver");
     if (deferred_solves) *deferred_solves = s->n_deferred;
     if (replays) *replays = s->n_replays;
+    return GATO_OK;
+}
+extern "C" int gato_get_solved_count_state(GatoSolver* s, int* mode, uint64_t* per_iteration_solves, uint32_t* per_iteration_left)
+{
+    if (!s) return fail(GATO_ERR_INVALID, "null solver");
+    if (mode) *mode = s->deferred_count ? GATO_COUNT_DEFERRED : GATO_COUNT_PER_ITERATION;
+    if (per_iteration_solves) *per_iteration_solves = s->n_periter;
+    if (per_iteration_left) *per_iteration_left = s->periter_left;
     return GATO_OK;
 }
 extern "C" int gato_set_graph_mode(GatoSolver* s, int enabled)
@@ -1527,10 +1574,18 @@ template<class M> static int mpc_step_impl(GatoSolver* s, GatoMpcStep* io)
         // reset_rho ahead of every solve (mpc_controller.py:229)
         HIPCHK(hipMemcpyAsync(s->bf.rho, s->d_rho_init, s->B * sizeof(float), hipMemcpyDeviceToDevice, st));
         HIPCHK(hipMemcpyAsync(s->bf.drho, s->d_drho_init, s->B * sizeof(float), hipMemcpyDeviceToDevice, st));
+        // GATO_MPC_TIME_SOLVE: the reference's sqp_time_us (bsqp.cuh:109,185) on this solve -- host clock, device-synchronised on both sides
+        const bool wall = (io->phases & GATO_MPC_TIME_SOLVE) != 0;
+        std::chrono::high_resolution_clock::time_point w0;
+        if (wall) { HIPCHK(hipStreamSynchronize(st)); w0 = std::chrono::high_resolution_clock::now(); }
         HIPCHK(hipEventRecord(s->mpc_ev0, st));
         const int rc = solve_impl<M>(s, s->d_xu_own, s->p.dt, s->d_xs_own, s->d_ref_own, st);
         if (rc != GATO_OK) return rc;
         HIPCHK(hipEventRecord(s->mpc_ev1, st));
+        if (wall) {
+            HIPCHK(hipStreamSynchronize(st));
+            io->solve_wall_us = std::chrono::duration<double, std::micro>(std::chrono::high_resolution_clock::now() - w0).count();
+        }
         if (selecting) {
             // evaluate_best_trajectory (mpc_controller.py:294-309): the PREVIOUS state and the previous best trajectory's first control under
             // every hypothesis against the state just measured
@@ -1554,6 +1609,7 @@ template<class M> static int mpc_step_impl(GatoSolver* s, GatoMpcStep* io)
     io->best = plan ? (int32_t)rec[s->nx + 3] : 0;
     io->solve_us = 0.0;
     io->plant_us = 0.0;
+    if (!(plan && (io->phases & GATO_MPC_TIME_SOLVE))) io->solve_wall_us = 0.0;
     if (advance) {
         f32_t ms = 0;
         HIPCHK(hipEventElapsedTime(&ms, s->mpc_ev2, s->mpc_ev3));
@@ -1761,7 +1817,13 @@ extern "C" int gato_get_stage_times_us(GatoSolver* s, double* out7)
 }
 
 extern "C" const char* gato_last_error(void) { return g_err.c_str(); }
-extern "C" const char* gato_version(void) { return "gato_amd 0.1.0 (gfx950)"; }
+// GATO_SRC_HASH: sha256 (first 16 hex digits) of kernels.hpp | rbd.hpp | solver.hip | robot_models.hpp as the Makefile saw them when THIS binary was
+// built (tools/source_hash.py, the same function bench.py applies to the tree it runs from): a stale .so says so on the bench line
+#ifndef GATO_SRC_HASH
+#define GATO_SRC_HASH "unknown"
+#endif
+extern "C" const char* gato_version(void) { return "gato_amd 0.1.0 (gfx950) src " GATO_SRC_HASH; }
+extern "C" const char* gato_source_hash(void) { return GATO_SRC_HASH; }
 extern "C" int gato_abi_version(void) { return GATO_ABI_VERSION; }
 extern "C" int gato_abi_real_size(void) { return (int)sizeof(float); }   // `float` is the real type here (real.hpp)
 static_assert(sizeof(GatoParams) == (kDouble ? 15 * 8 : 15 * 4), "GatoParams: 13 reals + 2 uint32 (padded to reals in the float64 build)");

@@ -34,9 +34,11 @@ def check_sharded_params(solve_ratio, world_size, coupled=False):
                          "counts solved trajectories over the whole batch (bsqp.cuh:165; solve_ratio=%g)" % (world_size, solve_ratio))
 
 
-def connect(solver, group=None):
+def connect(solver, group=None, timeout_s=120.0):
     """Collective over the ranks of `group`: gives `solver` (a gato_amd._lib.NativeSolver on this rank's device) the native RCCL communicator of
-    the sharded batch.  The 128-byte id travels through torch.distributed (any backend); everything after that is RCCL inside the library."""
+    the sharded batch.  The 128-byte id travels through torch.distributed (any backend); everything after that is RCCL inside the library.
+    Fails on EVERY rank or on none: RCCL missing (step 1), ncclCommInitRank failing on one rank (step 3) and the count-mode agreement (step 4)
+    are each compared across the ranks over torch.distributed before the next step; on a failure every rank drops its communicator and raises."""
     import torch.distributed as dist
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     # 1. agree that EVERY rank can open RCCL before any rank enters a collective of its own: gato_comm_available proves librccl.so loads and
@@ -54,22 +56,81 @@ def connect(solver, group=None):
     bad = {r: f for r, f in enumerate(flags) if f is not None}
     if bad:
         raise RuntimeError("RCCL is not available on rank(s) %s -- no rank initialises a communicator" % bad)   # raised on every rank alike
-    # 2. rank 0's id to everybody (rank 0 always broadcasts), then the collective initialisation
+    # 2. rank 0's id to everybody (rank 0 always broadcasts), then ncclCommInitRank ALONE (gato_comm_init_rank: no collective on the new communicator)
     box = [uid if rank == 0 else None]
     dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-    solver.comm_init(box[0], world, rank)
+    err = None
+    try:
+        solver.comm_init_rank(box[0], world, rank)
+    except Exception as e:   # noqa: BLE001
+        err = "%s: %s" % (type(e).__name__, e)
+    # 3. the ranks compare their outcomes over torch.distributed BEFORE anyone issues a collective on the new communicator: a rank whose
+    #    initialisation failed after the probe passed (a sick device, RCCL refusing its arguments) would otherwise leave the others inside the
+    #    first all-reduce for good.  Bounded: a rank that never arrives (it died) turns into an error here, not a hang.
+    bad = _agree(err, world, group, timeout_s, "gato_comm_init_rank")
+    if bad:
+        _drop(solver)
+        raise RuntimeError("the communicator could not be initialised on rank(s) %s -- every rank drops it" % bad)
+    # 4. the first collective on the new communicator: the ranks agree on the solved-count mode (a disagreement fails on every rank alike)
+    try:
+        solver.comm_confirm()
+    except Exception as e:   # noqa: BLE001
+        err = "%s: %s" % (type(e).__name__, e)
+    bad = _agree(err, world, group, timeout_s, "gato_comm_confirm")
+    if bad:
+        _drop(solver)
+        raise RuntimeError("the ranks did not agree on the solved-count mode / rank(s) %s failed -- every rank drops the communicator" % bad)
     return solver
+
+
+def _drop(solver):
+    try:
+        solver.comm_destroy()
+    except Exception:   # noqa: BLE001
+        pass
+
+
+def _agree(err, world, group, timeout_s, what):
+    """{rank: reason} of the ranks that reported a failure (empty: none), the same on every rank; a rank that does not report within timeout_s
+    counts as failed on the ranks that waited for it."""
+    import datetime
+    import torch
+    import torch.distributed as dist
+    # a fixed-size tensor (not an object collective): works asynchronously on every backend, so the wait can be bounded
+    dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+    mine = torch.zeros(257, dtype=torch.uint8)
+    if err is not None:
+        raw = err.encode("utf-8", "replace")[:256]
+        mine[0] = 1
+        mine[1:1 + len(raw)] = torch.tensor(list(raw), dtype=torch.uint8)
+    mine = mine.to(dev)
+    rows = [torch.zeros_like(mine) for _ in range(world)]
+    try:
+        work = dist.all_gather(rows, mine, group=group, async_op=True)
+        if not work.wait(datetime.timedelta(seconds=timeout_s)):
+            raise RuntimeError("timed out")
+        if dev == "cuda":
+            torch.cuda.current_stream().synchronize()
+    except Exception as e:   # noqa: BLE001
+        raise RuntimeError("a rank did not report its %s outcome within %.0f s (%s): the job cannot continue" % (what, timeout_s, e))
+    bad = {}
+    for r, row in enumerate(rows):
+        row = row.cpu()
+        if int(row[0]):
+            bad[r] = bytes(row[1:].tolist()).rstrip(b"\0").decode("utf-8", "replace")
+    return bad
 
 
 class PackedResults:
     """Rank-local result buffer [B*TRAJ iterates | B merits] + its gathered image, both resident on `device`."""
 
-    def __init__(self, B_local, traj, world_size, device="cpu"):
+    def __init__(self, B_local, traj, world_size, device="cpu", own_image=False):
+        """own_image: a gathered image of its own even for ONE rank (a one-rank communicator then really runs its ncclAllGather: bench.py --one-rank-comm)"""
         import torch
         self.B, self.traj, self.world = int(B_local), int(traj), int(world_size)
         self.n = self.B * self.traj + self.B
         self.local = torch.zeros(self.n, dtype=torch.float32, device=device)
-        self.gathered = torch.zeros(self.world * self.n, dtype=torch.float32, device=device) if self.world > 1 else self.local
+        self.gathered = torch.zeros(self.world * self.n, dtype=torch.float32, device=device) if (self.world > 1 or own_image) else self.local
 
     @property
     def xu(self):       # [B, TRAJ] view the solver iterates in place
@@ -82,7 +143,7 @@ class PackedResults:
     def all_gather(self, group=None, solver=None, stream=0):
         """the ONE data-path collective of a solve.  solver (connected): ncclAllGather on its communicator, enqueued on `stream` (a raw
         hipStream_t); otherwise torch.distributed on torch's current stream."""
-        if self.world > 1:
+        if self.world > 1 or (solver is not None and self.gathered is not self.local):
             if solver is not None:
                 solver.gather_results(self.local.data_ptr(), self.gathered.data_ptr(), self.n, stream)
             else:

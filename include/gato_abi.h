@@ -151,6 +151,7 @@ int gato_select_best_device(GatoSolver* s, const gato_real* d_x_last, const gato
  * The host sends the reference window and the hypotheses and reads back {x, end effector, best index, selection errors, solve time}. */
 #define GATO_MPC_ADVANCE 1 /* the plant: `plant_steps` RK4 steps of size sim_dt from the session's state */
 #define GATO_MPC_PLAN 2    /* prepare + reset_rho + solve + selection + take the best row */
+#define GATO_MPC_TIME_SOLVE 4   /* with PLAN: also fill solve_wall_us (two extra host waits around the solve) */
 typedef struct GatoMpcStep {
     uint32_t struct_size;    /* in: sizeof(GatoMpcStep) as the CLIENT was compiled; the library refuses any other value (a header that gained a field
                               * must not make the library write past an older client's struct) */
@@ -170,6 +171,10 @@ typedef struct GatoMpcStep {
     int32_t best;            /* selected row */
     double solve_us;         /* device time of the SQP solve (hipEvents around its launches); 0 without PLAN */
     gato_real* errors;       /* [B] host or NULL: the selection's per-hypothesis errors */
+    double solve_wall_us;    /* out, only with GATO_MPC_TIME_SOLVE in `phases`: HOST wall clock around the solve alone -- the stream is drained, the clock started,
+                              * the solve enqueued, the stream drained again, the clock stopped: the reference's `sqp_time_us` (bsqp.cuh:109,185: host
+                              * clock around the loop, device-synchronised), measured INSIDE the session on the session's own states.  The two extra
+                              * waits make the step slower: a measurement mode (tools/mpc_heatmap.py --solve-wall), 0 otherwise */
     double plant_us;         /* out: device time of the plant simulation (hipEvents around its launch); 0 without ADVANCE.  SIMULATING the plant
                               * is not controller latency: a loop that feeds measured latency back (mpc_controller.py:234-236 charges the time
                               * around solver.solve only) subtracts this from the wall time of the call */
@@ -211,12 +216,22 @@ int gato_ee_pos(GatoSolver* s, const gato_real* q, int n, gato_real* out);
  * RCCL is opened with dlopen here, never linked: a single-GPU host does not need it.
  *   gato_comm_unique_id   ncclGetUniqueId: 128 bytes rank 0 hands to the others (any transport)
  *   gato_comm_init        ncclCommInitRank on the solver's device; collective over all ranks; global_batch = world_size x B
+ *                         = gato_comm_init_rank + gato_comm_confirm, for a caller with no side channel between the ranks
+ *   gato_comm_init_rank   step 1: ncclCommInitRank alone -- NO collective is issued on the new communicator, so the ranks can compare their return
+ *                         codes over whatever transport carried the id and ALL drop (gato_comm_destroy) an initialisation that failed on any of them
+ *                         (gato_amd/sharding.py:connect does; a rank that fails here cannot leave its peers inside a collective)
+ *   gato_comm_confirm     step 2, collective on the new communicator: the ranks agree on the solved-count mode (below); sharded solves on the handle
+ *                         return GATO_ERR_INVALID until it has succeeded.  A disagreement fails on every rank alike and every rank drops its
+ *                         communicator; any other failure (allocation, HIP, RCCL) is the failing rank's own -- its message is kept, its communicator
+ *                         dropped, and the peers must gato_comm_destroy theirs
  *   gato_gather_results   ncclAllGather of `count` reals per rank on `stream`: the one data-path collective of a solve (packed iterates + merits)
  *   gato_comm_available   0 when librccl can be opened and has every entry point used here; no RCCL call is made (a side-effect-free probe: every
  *                         rank calls it before ANY rank enters gato_comm_init, so that the ranks fail together or not at all) */
 int gato_comm_available(void);
 int gato_comm_unique_id(char* out128);
 int gato_comm_init(GatoSolver* s, const char* id128, int world_size, int rank, int64_t global_batch);
+int gato_comm_init_rank(GatoSolver* s, const char* id128, int world_size, int rank, int64_t global_batch);
+int gato_comm_confirm(GatoSolver* s);
 int gato_comm_destroy(GatoSolver* s);
 int gato_gather_results(GatoSolver* s, const gato_real* d_local, gato_real* d_all, uint64_t count, void* stream);
 /* How a sharded solve learns the whole batch's solved count (the exit rule of bsqp.cuh:165 is the only coupling between the shards):
@@ -231,12 +246,16 @@ int gato_gather_results(GatoSolver* s, const gato_real* d_local, gato_real* d_al
  * host wait would invalidate the capture.  After a replay the next 8 sharded solves count per iteration (doubling up to 1024 while replays keep
  * coming): a batch whose exit rule fires on every solve pays the speculative pass once in a while, not every time.
  * Every rank of a communicator must be in the same mode: gato_comm_init checks it (and fails on every rank alike), and with a communicator
- * gato_set_solved_count_mode is COLLECTIVE -- every rank calls it, with the same mode.
- * gato_get_shard_stats: speculative solves run so far, and how many of them had to be replayed. */
+ * gato_set_solved_count_mode is COLLECTIVE -- every rank calls it, with the same mode; when the ranks turn out to disagree (or the call fails on
+ * this rank) the handle keeps the mode it had, so mixed modes are never left behind.
+ * gato_get_shard_stats: speculative solves run so far, and how many of them had to be replayed.
+ * gato_get_solved_count_state: the mode the handle is in, the sharded solves that counted per iteration so far (because of the mode, a stream
+ * capture, or the back-off after a replay -- none of them appears in gato_get_shard_stats), and how many more the back-off will take that way. */
 #define GATO_COUNT_PER_ITERATION 0
 #define GATO_COUNT_DEFERRED 1
 int gato_set_solved_count_mode(GatoSolver* s, int mode);
 int gato_get_shard_stats(GatoSolver* s, uint64_t* deferred_solves, uint64_t* replays);
+int gato_get_solved_count_state(GatoSolver* s, int* mode, uint64_t* per_iteration_solves, uint32_t* per_iteration_left);
 /* TEST HOOK: a shard of a global_batch-trajectory batch WITHOUT a communicator: the other shards' solved counts per SQP iteration are given
  * (global_batch = 0 ends it).  Lets a 1-GPU box check the sharded exit rule against the unsharded solve. */
 int gato_debug_set_remote_solved(GatoSolver* s, const uint32_t* per_iter, int n, int64_t global_batch);
@@ -258,9 +277,12 @@ int gato_get_stage_times_us(GatoSolver* s, double* out7);
 
 const char* gato_last_error(void);
 const char* gato_version(void);
+/* sha256[:16] of the kernel sources THIS binary was built from (gato_amd/csrc/Makefile: -DGATO_SRC_HASH from tools/source_hash.py; "unknown" for a
+ * build that bypassed the Makefile).  bench.py reports it next to the hash of the tree it runs from: a stale library cannot pass for a fresh one. */
+const char* gato_source_hash(void);
 /* Bumped whenever a struct or an entry point of this header changes shape; every binding compares it with the GATO_ABI_VERSION it was written
  * against at load time (include/bsqp.hpp, gato_amd/csrc/pyext.cpp, gato_amd/_lib.py) and refuses a library of another version. */
-#define GATO_ABI_VERSION 5
+#define GATO_ABI_VERSION 6
 int gato_abi_version(void);
 /* sizeof(gato_real) of the LIBRARY: 4 for libgato_hip.so, 8 for libgato_hip_f64.so (a client compiled with the other setting must not call it further) */
 int gato_abi_real_size(void);

@@ -24,6 +24,27 @@ def test_source_hash_names_the_kernel_sources():
         pytest.skip("profiles/pmc_summary.json was measured on other kernel sources (%s): rerun tools/profile_round.sh + tools/summarize_pmc.py" % pmc["build"])
 
 
+def test_the_library_carries_the_hash_of_the_sources_it_was_built_from():
+    """gato_source_hash() / gato_version() of the LOADED libgato_hip.so (and of its float64 build) = tools/source_hash.py over this tree: the Makefile
+    bakes it in (-DGATO_SRC_HASH), bench.py prints both and fails `solution_ok` when they differ -- a stale .so cannot produce a clean line."""
+    import ctypes
+    sys.path.insert(0, ROOT)
+    import bench
+    from gato_amd import _lib
+    from tools.source_hash import source_hash
+    assert bench.source_hash() == source_hash()
+    for f64 in (False, True):
+        L = _lib.load(f64)
+        L.gato_source_hash.restype = ctypes.c_char_p
+        got = L.gato_source_hash().decode()
+        assert got == source_hash(), "the built library is stale (%s vs the tree's %s): make -C gato_amd/csrc" % (got, source_hash())
+        assert got in L.gato_version().decode()
+    assert bench.library_build() == source_hash()
+    # both places bench.py uses it: the pmc block and the solution checks
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert '"library_build": lib_build' in src and 'checks["library_built_from_this_tree"]' in src
+
+
 def test_refuses_to_run_without_a_device():
     import torch
     if torch.cuda.is_available():
@@ -99,11 +120,13 @@ def test_two_rank_rehearsal_of_the_multi_gpu_branch(extra, count_mode):
     d = json.loads(lines[0])
     try:
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-        with open(os.path.join(ROOT, "gpurun_out", "r05_bench_rehearsal.jsonl"), "a") as f:
+        with open(os.path.join(ROOT, "gpurun_out", "r06_bench_rehearsal.jsonl"), "a") as f:
             f.write(json.dumps({"cmd": " ".join(cmd[1:]), "GATO_SOLVED_COUNT": count_mode, "line": d, "stderr_tail": r.stderr[-600:]}) + "\n")
     except OSError:
         pass
     assert d["n_gpus"] == 2 and d["steps"] == 4 and d["warmup"] == 1 and d["scaling"] == "weak" and d["solution_ok"] is True
+    assert d["metric"].startswith("REHEARSAL")                     # a rehearsal line can never pass for the headline
+    assert d["solution_checks"]["library_built_from_this_tree"] is True and "failed_on_ranks" not in d["solution_checks"]   # the AND over both ranks
     iters = d["config"]["sqp_iters_per_solve"]
     assert iters == 10 and d["config"]["global_batch"] == 2 * B and d["config"]["batch_per_gpu"] == B
     assert abs(d["value"] - 2 * B * iters / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]          # both ranks' work over the max-over-ranks time
@@ -122,6 +145,42 @@ def test_two_rank_rehearsal_of_the_multi_gpu_branch(extra, count_mode):
         if hparam:
             assert all(abs(s_["cost_tuple"][k] - v) <= 1e-6 * abs(v) for k, v in HPARAM_COST_GRID[rk].items())   # rank g = shard g = cost tuple g
     assert mg["shards"][0]["first_ref_xyz"] != mg["shards"][1]["first_ref_xyz"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [(), ("--workload", "hparam", "--plant", "iiwa14", "--knots", "16", "--batch", "64")], ids=["fig8", "hparam"])
+def test_rows_of_another_rank_through_the_one_rank_communicator(extra):
+    """--as-rank R --of G --one-rank-comm: one process on one device solves the rows rank R of a G-rank job would hold, through the library's OWN
+    communicator with world size 1 (snapshot, speculative solve, ncclAllReduce of the count vector, the host wait, ncclAllGather on the communication
+    stream in every timed step) -- what tools/scaling_prediction.py runs for R = 0..7.  The line says whose rows they are and how the count travelled."""
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    hparam = "hparam" in extra
+    B = 64 if hparam else 128
+    args = list(extra) if hparam else ["--batch", str(B)]
+    r = _run("--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--as-rank", "3", "--of", "8", "--one-rank-comm", *args)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["solution_ok"] is True and "rank 3 of 8" in d["metric"] and "one-rank communicator" in d["metric"]
+    assert d["config"]["rows_of_rank"] == {"rank": 3, "of": 8} and d["config"]["global_batch"] == B
+    assert abs(d["value"] - B * 10 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    mg = d["multi_gpu"]
+    assert "ncclAllGather" in mg["collective"] and mg["solved_count"].startswith("deferred") and "one_rank_comm" in mg
+    # every solve of the run (warm-up, timed, the no-gather loop, the profiled one) ran speculatively, none was replayed, none counted per iteration
+    assert mg["solves_by_count_form"]["speculative"] >= 4 + 1 + 2 + 1 and mg["solves_by_count_form"]["replayed"] == 0 and mg["solves_by_count_form"]["per_iteration"] == 0
+    assert mg["gather_ms"]["max_over_ranks"] > 0 and mg["solve_ms_without_gather"] > 0
+    # the same rows without the communicator: the same iterates' statistics (the sharded path does not change a trajectory), and the plain loop is not slower
+    r2 = _run("--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--as-rank", "3", "--of", "8", *args)
+    assert r2.returncode == 0, r2.stderr[-3000:]
+    d2 = json.loads([l for l in r2.stdout.splitlines() if l.strip().startswith("{")][0])
+    assert "multi_gpu" not in d2 and d2["config"]["mean_pcg_iters"] == d["config"]["mean_pcg_iters"]
+    assert d2["config"]["sum_over_launches_of_max_pcg_iters"] == d["config"]["sum_over_launches_of_max_pcg_iters"]
+    # ... and they are NOT rank 0's rows
+    r0 = _run("--steps", "2", "--warmup", "1", "--no-cpu-baseline", *args)
+    d0 = json.loads([l for l in r0.stdout.splitlines() if l.strip().startswith("{")][0])
+    assert d0["config"]["rows_of_rank"] == {"rank": 0, "of": 1} and d0["config"]["mean_pcg_iters"] != d["config"]["mean_pcg_iters"]
 
 
 def test_roofline_arithmetic_of_the_bench_line():

@@ -146,3 +146,82 @@ def test_shard_bounds():
         check_sharded_params(0.5, 2)              # uncoupled shards: refused, not approximated ...
     with pytest.raises(ValueError):
         check_sharded_params(1.0, 8)              # ... also at solve_ratio 1 (a converged shard would stop stepping its rows early)
+
+
+class _FakeSolver:
+    """what sharding.connect needs of a solver, with a scripted failure: the protocol between the ranks is the thing under test"""
+
+    def __init__(self, rank, fail_at):
+        self.rank, self.fail_at, self.calls = rank, fail_at, []
+
+    def comm_available(self):
+        self.calls.append("available")
+        return "librccl.so missing (scripted)" if self.fail_at == "available" else None
+
+    def comm_unique_id(self):
+        self.calls.append("unique_id")
+        return bytes(range(128))
+
+    def comm_init_rank(self, uid, world, rank):
+        self.calls.append("init_rank")
+        assert uid == bytes(range(128)) and rank == self.rank
+        if self.fail_at == "init_rank":
+            raise RuntimeError("ncclCommInitRank: unhandled system error (scripted, rank %d)" % rank)
+
+    def comm_confirm(self):
+        self.calls.append("confirm")
+        if self.fail_at == "confirm":
+            raise RuntimeError("hipErrorOutOfMemory (scripted)")
+
+    def comm_destroy(self):
+        self.calls.append("destroy")
+
+
+def _connect_worker(rank, world, port, fail_rank, fail_at, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gato_amd.sharding import connect
+    s = _FakeSolver(rank, fail_at if rank == fail_rank else None)
+    try:
+        connect(s, timeout_s=30.0)
+        out = "ok"
+    except RuntimeError as e:
+        out = str(e)
+    q.put((rank, out, s.calls))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fail_at", [None, "available", "init_rank", "confirm"])
+def test_connect_fails_on_every_rank_or_on_none(fail_at):
+    """sharding.connect: whatever step fails on ONE rank (RCCL missing, ncclCommInitRank after the probe passed, the count-mode agreement), BOTH
+    ranks raise with that rank and its reason, the step after it is never entered on any rank (no rank is left inside a collective on a
+    communicator whose peer is gone), and every rank that had a communicator dropped it."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_connect_worker, args=(r, world, port, 1, fail_at, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict()
+    for _ in range(world):
+        r, out, calls = q.get(timeout=120)
+        got[r] = (out, calls)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(world):
+        out, calls = got[r]
+        if fail_at is None:
+            assert out == "ok" and calls == ["available"] + (["unique_id"] if r == 0 else []) + ["init_rank", "confirm"]
+            continue
+        assert out != "ok" and "1:" in out.replace("{", "").replace(" ", "") and "scripted" in out, out     # the failing rank and ITS reason, on both ranks
+        if fail_at == "available":
+            assert "init_rank" not in calls and "destroy" not in calls
+        elif fail_at == "init_rank":
+            assert "confirm" not in calls and calls[-1] == "destroy"      # nobody issued a collective on the half-built communicator
+        else:
+            assert calls[-2:] == ["confirm", "destroy"]

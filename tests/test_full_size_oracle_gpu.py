@@ -19,7 +19,7 @@ float64 steps as often, as the fp32 oracle does.)  Asserted:
                      within +-1 on >= 99 %
   every row          finite; initial merit to 1e-5; the HIP path is as close to float64 as the fp32 oracle is: median distance <= 2 x the
                      oracle's (+1e-5), and it follows the float64 steps on as many rows (-3 %)
-Measured numbers go to gpurun_out/r05_parity_full_size.jsonl (copied to profiles/r05_parity_full_size.json)."""
+Measured numbers go to gpurun_out/r06_parity_full_size.jsonl (copied to profiles/r06_parity_full_size.json; round 5's: profiles/r05_parity_full_size.json)."""
 import json
 import os
 
@@ -47,7 +47,7 @@ def _report(**kw):
     try:
         d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
         os.makedirs(d, exist_ok=True)
-        with open(os.path.join(d, "r05_parity_full_size.jsonl"), "a") as f:
+        with open(os.path.join(d, "r06_parity_full_size.jsonl"), "a") as f:
             f.write(json.dumps({k: (v if isinstance(v, (str, bool, int, list)) else float(v)) for k, v in kw.items()}) + "\n")
     except OSError:
         pass
@@ -116,8 +116,16 @@ def _check(case, tag, plant, N, B, p, out, pcg_counts, xu_scale=1.0):
     # one row of 1024, 34 against 37 iterations, 8.9e-3; the other 1023 rows <= 4.7e-4).  The maximum is taken over the rows with EQUAL counts;
     # rows with other counts (at most 1 %, asserted below) get 10 x the bound
     eq = (dp == 0) if pcg_counts else np.ones(B, bool)
+    if enough:
+        assert (use & eq).any(), "%s: no resolved row has the oracle's PCG count -- nothing to take the maximum over (a count shift on every row is a regression)" % case
     mx, p99, med = (float(ego[use & eq].max()), float(np.quantile(ego[use], 0.99)), float(np.median(ego[use]))) if enough else (0.0, 0.0, 0.0)
     mx_other = float(ego[use & ~eq].max()) if (use & ~eq).any() else 0.0
+    # the 10 x class is for the odd row that sits ON the exit threshold, not for a kernel that drifts: at most 1 % of the rows may have another count
+    # than the oracle, by at most 3 iterations (measured: C2 and seven C4 shards none, C4 shard 2 one row of 1024 at 34 vs 37, C3 two rows of 256 by
+    # one) -- a regression that shifts counts on more rows, or further, fails HERE instead of being absorbed by the wider bound
+    if pcg_counts and enough:
+        other = use & ~eq
+        assert other.sum() <= max(1, int(0.01 * B)) and (dp[other].max() if other.any() else 0) <= 3, (int(other.sum()), dp[other].tolist()[:10])
     _report(test=tag, case=case, plant=plant, N=N, B=B, resolved_rows=int(resolved.sum()), steps_equal_on_resolved=int(use.sum()), near_ties=ties, departures=len(departs),
             xu_vs_fp32_oracle_max=mx, xu_vs_fp32_oracle_max_rows_with_other_pcg_counts=mx_other, xu_vs_fp32_oracle_p99=p99, xu_vs_fp32_oracle_median=med,
             rows_within_1e_4_of_the_fp32_oracle=float((ego[use] <= 1e-4).mean()) if enough else 0.0,      # the north-star's "iterate match within 1e-4 rel", row by row
@@ -354,3 +362,93 @@ def test_first_iteration_decisions_on_every_shard_of_c4(shard):
     """rows 1024 r .. 1024 r + 1023 of C4 through the whole first iteration at the workload's own settings (shard 0 = C2 above)"""
     plant, N, B, p, out = _run("C4", shard=shard, max_sqp_iters=1)
     _check("C4", "default_1it_shard%d" % shard, plant, N, B, p, out, pcg_counts=True, xu_scale=3.0)
+
+
+# ---- the sweep's ill-conditioned stages, settled in float64 (round-5 review, weak 1) ------------------------------------------------------
+# In fp32 the sweep's gamma, P^-1 and dz can only be held to "as noisy as the fp32 oracle" (above): cond(theta + rho I) ~ 4e9 and a 1e7-fold
+# cancellation in dz_u put single precision's rounding at the size of the result on the worst rows (shards 2 / 3: the a-priori dz bound allows
+# 87 % / 96 % of max|dz|).  Conditioning cannot touch the float64 build: the SAME kernel sources compiled with double (libgato_hip_f64.so) against
+# the float64 oracle from IDENTICAL inputs leave cond x 1e-16 ~ 1e-7.  This is the check that says "the HIP formulas ARE the oracle's" on every
+# trajectory / block of all 8 sweep shards at full size (iiwa14 N = 64, B = 512, per-trajectory rho over nine decades):
+#   merit of the warm start, KKT blocks, (Q + rho I)^-1, R^-1, S, the 8 merits from the oracle's dz        <= 1e-9  (per buffer / per trajectory)
+#   gamma (per trajectory), P^-1 (EVERY (trajectory, knot) block, main and stair), dz from the oracle's lambda (per trajectory)   <= 1e-6
+#   step, rho, drho, merit_cur and the new iterate from the oracle's merit table                            bit for bit
+# schur_linsys.cuh:121-128 (gamma), :150-164 + :213-260 (P^-1 and its stair blocks), :316-431 (dz).
+def _blocks3(a, b, nx):
+    """S / P^-1 in the reference's layout [B][N][nx][3 nx]: per (trajectory, knot, left | main | right) block max|a - b| / max|b| (zero blocks
+    -- row 0's left, row N-1's right -- must be zero on both sides), max over all of them"""
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    worst = 0.0
+    for j in range(3):
+        aa, bb = a[..., j * nx:(j + 1) * nx], b[..., j * nx:(j + 1) * nx]
+        den = np.abs(bb).max(axis=(2, 3))
+        num = np.abs(aa - bb).max(axis=(2, 3))
+        assert np.all(num[den == 0] == 0)
+        worst = max(worst, float((num[den > 0] / den[den > 0]).max()))
+    return worst
+
+
+@pytest.mark.parametrize("shard", range(8))
+def test_float64_build_stage_by_stage_on_every_sweep_shard(shard):
+    from gato_amd._lib import NativeSolver
+    from oracle.oracle import OracleSolver
+    plant, N, B, pr, p, dt = _problem("C5", shard)
+    nt = os.cpu_count() or 1
+    nat = NativeSolver(plant, N, B, f64=True, dt=dt, **p)
+    orc = OracleSolver(plant, N, B, dt=dt, threads=nt, f64=True, **p)
+    for s in (nat, orc):
+        s.set_rho_penalty_batch(pr["rho"])
+    xu, xs, ref = pr["xu"], pr["x_s"], pr["ref"]
+    nx, nu = nat.nx, nat.nu
+    m = {}
+    nat.stage("merit1", xu, dt, xs, ref)
+    m0 = orc.merit(xu, xs, ref, dt, num_alphas=1, zero_dz=True)[:, 0]
+    m["merit0"] = _rows(nat.read("merit_cur")[:, None], m0[:, None]).max()
+    nat.stage("kkt", xu, dt, xs, ref)
+    orc.setup_kkt(xu, xs, ref, dt)
+    dk = nat.dense_kkt(dt)
+    assert dk["A"].dtype == np.float64 and orc.buf("A").dtype == np.float64
+    for name in ("A", "B", "R", "r"):
+        m[name] = _buf(dk[name][:, :N - 1], orc.buf(name)[:, :N - 1])
+    for name in ("c", "Q", "q"):
+        m[name] = _buf(dk[name], orc.buf(name))
+    nat.stage("schur", xu, dt, xs, ref)
+    orc.form_schur()
+    dk = nat.dense_kkt(dt)
+    m["Qinv"] = _buf(dk["Qinv"], orc.buf("Qinv"))
+    m["Rinv"] = _buf(dk["Rinv"][:, :N - 1], orc.buf("Rinv")[:, :N - 1])
+    got = {name: nat.read(name).reshape(orc.buf(name).shape) for name in ("S", "Pinv", "gamma")}
+    m["S"] = _buf(got["S"], orc.buf("S"))
+    m["S_worst_block"] = _blocks3(got["S"], orc.buf("S"), nx)
+    m["Pinv_worst_block"] = _blocks3(got["Pinv"], orc.buf("Pinv"), nx)          # every block: main diagonal and both stair off-diagonals of every knot
+    m["gamma_rows"] = float(_rows(got["gamma"], orc.buf("gamma")).max())
+    orc.pcg()
+    lam = orc.buf("lambda")
+    nat.write("lambda", lam)
+    nat.stage("dz", xu, dt, xs, ref)
+    orc.compute_dz()
+    dz = orc.buf("dz")
+    m["dz_rows"] = float(_rows(nat.read("dz").reshape(B, -1), dz).max())
+    m["q_res"] = _buf(nat.read("q").reshape(B, N, nx), orc.buf("q"))
+    m["r_res"] = _buf(nat.read("r").reshape(B, N, nu), orc.buf("r"))
+    nat.write("dz", dz)
+    nat.stage("merit8", xu, dt, xs, ref)
+    m8 = orc.merit(xu, xs, ref, dt, num_alphas=8)
+    m["merit8"] = _rows(nat.read("merit").reshape(B, 8), m8).max()
+    rho0, drho0 = orc.buf("rho"), orc.buf("drho")
+    for s_w in (nat.write, orc.set_buf):
+        s_w("merit", m8); s_w("merit_cur", m0); s_w("dz", dz); s_w("rho", rho0); s_w("drho", drho0)
+    xg = nat.stage("line_search", xu, dt, xs, ref)
+    xo = orc.line_search(xu)
+    step = orc.buf("step")
+    m["steps_taken"], m["distinct_steps"] = int((step > 0).sum()), int(len(np.unique(step)))
+    _report(test="stagewise_shard_f64", case="C5", shard=shard, plant=plant, N=N, B=B, rho_min=float(pr["rho"].min()), rho_max=float(pr["rho"].max()),
+             **{("err_" + k) if k not in ("steps_taken", "distinct_steps") else k: v for k, v in m.items()})
+    for name in ("merit0", "A", "B", "c", "Q", "q", "R", "r", "Qinv", "Rinv", "S", "S_worst_block", "merit8"):
+        assert m[name] <= 1e-9, (name, m)
+    for name in ("gamma_rows", "Pinv_worst_block", "dz_rows", "q_res", "r_res"):
+        assert m[name] <= 1e-6, (name, m)
+    for name in ("step", "rho", "drho", "merit_cur"):
+        np.testing.assert_array_equal(nat.read(name), orc.buf(name), err_msg=name)
+    np.testing.assert_array_equal(xg, xo)
+    assert (step > 0).any() and np.abs(xo - xu).max() > 0

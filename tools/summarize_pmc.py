@@ -30,10 +30,9 @@ SRC = ["gato_amd/csrc/kernels.hpp", "gato_amd/csrc/rbd.hpp", "gato_amd/csrc/solv
 
 
 def build_hash():
-    h = hashlib.sha256()
-    for f in SRC:
-        h.update(open(os.path.join(ROOT, f), "rb").read())
-    return h.hexdigest()[:16]
+    sys.path.insert(0, ROOT)
+    from tools.source_hash import source_hash   # the one definition (also baked into the libraries and printed by bench.py)
+    return source_hash()
 
 
 def short(name):
