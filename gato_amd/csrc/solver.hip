@@ -69,6 +69,7 @@ struct GatoSolver {
     // streaming pcg_kernel), whether it forms the stair off-diagonals itself (then schur2_kernel is not launched) and whether the
     // Schur complement is formed inside it.  Tuning overrides GATO_PCG_VARIANT / GATO_PCG_FOLD are read there, never in the solve loop.
     int pcg_choice, pcg_fold, pcg_fused, pcg_pair;
+    int pcg_quad = 0;   // EXPERIMENT (GATO_PCGS_QUAD=1): the quad form of the symmetric-storage kernel (pcgq_kernel, no fold) instead of pcgs_kernel
     int cus;   // compute units of the solver's device
     int pcg_rounds;   // > 1: the PCG workgroups are scheduled hardest-first (Buffers::order), see plan_pcg
     int32_t* d_order;
@@ -109,7 +110,15 @@ struct GatoSolver {
     int deferred_count = 1;
     float thresh_override = -1.f;      // >= 0: what exit_threshold() returns (the speculative run: +inf)
     float *d_snap_xu = nullptr, *d_snap_lambda = nullptr, *d_snap_rho = nullptr;   // snapshot of what a solve changes for good: xu | lambda | rho, drho
-    uint32_t* h_counts = nullptr;      // pinned: the reduced count vector, read by the host for the verdict
+    uint32_t* h_counts = nullptr;      // pinned, host-coherent: [max_iters reduced counts | sequence number], WRITTEN BY THE DEVICE (publish_counts_kernel) behind
+                                       // the reduction; the host spins on the sequence number: no copy engine, no interrupt between the reduction and the verdict
+    uint32_t* d_h_counts = nullptr;    // the device's address of h_counts
+    uint32_t verdict_seq = 0;
+    // a speculative solve whose verdict has not been taken yet (round 6).  gato_solve_device returns as soon as the solve, the reduction and the
+    // publication are ENQUEUED; the verdict is taken -- and the exact replay run, if the rule fired -- at the next entry point that reads or changes the
+    // handle's state or the solve's results (settle()).  Between the two the host is free: bench.py enqueues the PREVIOUS solve's gather there instead
+    // of with the device idle behind a host wait (profiles/r06_scaling_prediction.json: 87 -> see DESIGN section 5)
+    struct { bool active = false; float* d_xu = nullptr; float dt = 0; const float* d_xs = nullptr; const float* d_ref = nullptr; hipStream_t st = nullptr; uint32_t iters = 0; } pend;
     uint64_t n_replays = 0, n_deferred = 0;   // statistics: speculative solves run / of those replayed (gato_get_shard_stats)
     uint64_t n_periter = 0;            // sharded solves that shared the count per SQP iteration instead: the mode, a capture, or the back-off after a replay
     bool comm_confirmed = false;       // the ranks have agreed on the count mode over THIS communicator (gato_comm_confirm): sharded solves refuse before
@@ -166,6 +175,7 @@ extern "C" int gato_dims(int plant, int N, int* nq, int* nx, int* nu, int* traj)
 
 static int plan_pcg_dispatch(GatoSolver* s);
 static int sync_last(GatoSolver* s);
+static int settle(GatoSolver* s);
 static int create_impl(GatoSolver* s, int plant, int N, int B, const GatoParams* params)
 {
     s->plant = plant; s->N = N; s->B = B;
@@ -295,6 +305,7 @@ extern "C" int gato_destroy(GatoSolver* s)
 {
     if (!s) return GATO_OK;
     GUARD(s);
+    s->pend.active = false;   // a pending verdict dies with the handle (its stream is drained next; nobody will read the results)
     if (s->last_stream_valid) (void)hipStreamSynchronize(s->last_stream);
     if (s->comm) (void)gato_comm_destroy(s);
     if (s->d_ee_q) (void)hipFree(s->d_ee_q);
@@ -417,10 +428,20 @@ template<class M> static bool pcgs_grant(const GatoSolver* s)
     return grant_lds(reinterpret_cast<const void*>(&pcgs_kernel<M, 512, false>), pcgs_lds(s)) &&
            grant_lds(reinterpret_cast<const void*>(&pcgs_kernel<M, 512, true>), pcgs_lds(s));
 }
+static size_t pcgq_lds(const GatoSolver* s)
+{
+    const size_t T = 4 * (size_t)s->N, N = s->N, ch = s->nx / 2;
+    return ((size_t)2 * (N + 2) * 16 + 32 + (N + 1) * 2 * 16) * sizeof(float) + (4 * 2 * ch / 4) * T * sizeof(real4);
+}
 // fold: the kernel forms the stair off-diagonals itself (solve path); otherwise it reads the complete P^-1 (stage tests, GATO_PCG_FOLD=0)
 template<class M> static void launch_pcgs(GatoSolver* s, hipStream_t st, int sqp_iter, bool fold)
 {
     const int T = 4 * s->N;
+    if (s->pcg_quad) {
+        if (T == 256) hipLaunchKernelGGL((pcgq_kernel<M, 256>), dim3(s->B), dim3(T), pcgq_lds(s), st, s->bf, s->N, s->B, s->p.max_pcg_iters, sqp_iter);
+        else hipLaunchKernelGGL((pcgq_kernel<M, 512>), dim3(s->B), dim3(T), pcgq_lds(s), st, s->bf, s->N, s->B, s->p.max_pcg_iters, sqp_iter);
+        return;
+    }
     if (T <= 256) {
         if (fold) hipLaunchKernelGGL((pcgs_kernel<M, 256, true>), dim3(s->B), dim3(T), pcgs_lds(s), st, s->bf, s->N, s->B, s->p.max_pcg_iters, sqp_iter);
         else hipLaunchKernelGGL((pcgs_kernel<M, 256, false>), dim3(s->B), dim3(T), pcgs_lds(s), st, s->bf, s->N, s->B, s->p.max_pcg_iters, sqp_iter);
@@ -459,6 +480,15 @@ template<class M> static int plan_pcg(GatoSolver* s)
             case 1: fold = pcgc_grant_fold<M, 6>(s); break;
             case 4: fold = pcgc_grant_fold<M, 1, 4>(s); break;
             case 7: break;   // granted with the kernel (pcgs_grant)
+        }
+    }
+    {
+        const char* qe = getenv("GATO_PCGS_QUAD");
+        s->pcg_quad = 0;
+        if (qe && atoi(qe) != 0 && choice == 7 && (4 * s->N == 256 || 4 * s->N == 512) &&
+            grant_lds(4 * s->N == 256 ? reinterpret_cast<const void*>(&pcgq_kernel<M, 256>) : reinterpret_cast<const void*>(&pcgq_kernel<M, 512>), pcgq_lds(s))) {
+            s->pcg_quad = 1;
+            fold = false;   // the experiment reads the complete P^-1 (schur2_kernel runs)
         }
     }
     s->pcg_fold = fold ? 1 : 0;
@@ -980,7 +1010,7 @@ template<class M> static int enqueue_solve(GatoSolver* s, float dt, hipStream_t 
 }
 
 // async_only: the caller cannot take a host synchronisation inside the solve (stream capture): a sharded solve then shares the count per iteration
-template<class M> static int solve_impl(GatoSolver* s, float* d_xu, float dt, const float* d_xs, const float* d_ref, hipStream_t st, bool async_only = false)
+template<class M> static int solve_impl(GatoSolver* s, float* d_xu, float dt, const float* d_xs, const float* d_ref, hipStream_t st, bool async_only = false, bool lazy_ok = false)
 {
     Buffers& bf = s->bf;
     const int B = s->B;
@@ -1010,12 +1040,15 @@ template<class M> static int solve_impl(GatoSolver* s, float* d_xu, float dt, co
         if (!s->d_snap_lambda && (rc = dalloc(s, &s->d_snap_lambda, (size_t)B * s->vecp, false)) != GATO_OK) return rc;
         if (!s->d_snap_rho && (rc = dalloc(s, &s->d_snap_rho, 2 * (size_t)B, false)) != GATO_OK) return rc;
         if (!s->h_counts) {
-            void* hc = nullptr;
-            HIPCHK(hipHostMalloc(&hc, s->max_iters_alloc * sizeof(uint32_t), hipHostMallocDefault));
+            void *hc = nullptr, *dc = nullptr;
+            HIPCHK(hipHostMalloc(&hc, (s->max_iters_alloc + 1) * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent));
+            if (hipHostGetDevicePointer(&dc, hc, 0) != hipSuccess) { (void)hipHostFree(hc); return fail(GATO_ERR_HIP, "hipHostGetDevicePointer (the verdict's pinned counts)"); }
+            memset(hc, 0, (s->max_iters_alloc + 1) * sizeof(uint32_t));
             s->h_counts = static_cast<uint32_t*>(hc);
+            s->d_h_counts = static_cast<uint32_t*>(dc);
         }
     }
-    const size_t bx = (size_t)B * s->traj * sizeof(float), bl = (size_t)B * s->vecp * sizeof(float), bb = (size_t)B * sizeof(float);
+    const size_t bx = (size_t)B * s->traj * sizeof(float), bl = (size_t)B * s->vecp * sizeof(float);
     hipLaunchKernelGGL(snapshot_kernel, dim3(s->cus > 0 ? s->cus * 4 : 256), dim3(256), 0, st, s->d_snap_xu, (const float*)d_xu, (uint32_t)(bx / sizeof(float)),
                        s->d_snap_lambda, (const float*)bf.lambda, (uint32_t)(bl / sizeof(float)), s->d_snap_rho, (const float*)bf.rho, (const float*)bf.drho, (uint32_t)B);
     s->thresh_override = INFINITY;
@@ -1024,8 +1057,44 @@ template<class M> static int solve_impl(GatoSolver* s, float* d_xu, float dt, co
     if (rc != GATO_OK) return rc;
     rc = reduce_solved_all(s, st, (int)iters);
     if (rc != GATO_OK) return rc;
-    HIPCHK(hipMemcpyAsync(s->h_counts, bf.num_solved, iters * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));   // the one host wait of a deferred solve: the verdict must be known before anyone consumes the results
+    // the reduced vector and, behind a system-scope fence, a fresh sequence number straight into host memory
+    s->verdict_seq++;
+    if (s->verdict_seq == 0) s->verdict_seq = 1;
+    hipLaunchKernelGGL(publish_counts_kernel, dim3(1), dim3(64), 0, st, s->d_h_counts, (const uint32_t*)bf.num_solved, iters, s->max_iters_alloc, s->verdict_seq);
+    HIPCHK(hipGetLastError());
+    s->pend.active = true;
+    s->pend.d_xu = d_xu; s->pend.dt = dt; s->pend.d_xs = d_xs; s->pend.d_ref = d_ref; s->pend.st = st; s->pend.iters = iters;
+    // lazy: only gato_solve_device leaves the verdict to the next entry point; every other caller (gato_solve, the MPC session) goes on to use
+    // the results on this stream at once
+    return lazy_ok ? GATO_OK : settle(s);
+}
+
+// The verdict of the pending speculative solve, and its exact replay if the exit rule fired.  Called at the top of every entry point that reads or
+// changes what the solve reads or writes (through sync_last, and by the stream-ordered ones: gato_solve_device, gato_reset_async,
+// gato_copy_final_merit_device, the *_device helpers).  NOT by gato_gather_results: it touches nothing of the solver's (the caller orders it).
+template<class M> static int settle_impl(GatoSolver* s)
+{
+    Buffers& bf = s->bf;
+    const int B = s->B;
+    const uint32_t iters = s->pend.iters;
+    hipStream_t st = s->pend.st;
+    s->pend.active = false;
+    // the one host wait of a deferred solve: spin on the sequence number the device writes behind the reduction (a hipStreamSynchronize here took the
+    // interrupt path: tens of microseconds with the device idle); the stream is queried now and then so that a device fault ends the wait
+    volatile uint32_t* seq = s->h_counts + s->max_iters_alloc;
+    for (uint64_t spins = 0; *seq != s->verdict_seq; spins++) {
+        if ((spins & 0xfffff) == 0xfffff) {
+            const hipError_t q = hipStreamQuery(st);
+            if (q == hipSuccess) {   // everything on the stream has run: the number must be there (give the write a moment to land), else something is wrong
+                HIPCHK(hipStreamSynchronize(st));
+                if (*seq != s->verdict_seq) return fail(GATO_ERR_HIP, "the deferred solve finished without publishing its solved counts");
+                break;
+            }
+            if (q != hipErrorNotReady) return fail(GATO_ERR_HIP, std::string("waiting for the verdict of a deferred solve: ") + hipGetErrorString(q));
+        }
+        __builtin_ia32_pause();
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
     s->n_deferred++;
     const float thresh = exit_threshold_exact(s);
     bool fired = false;
@@ -1035,16 +1104,25 @@ template<class M> static int solve_impl(GatoSolver* s, float* d_xu, float dt, co
     s->n_replays++;
     s->periter_left = s->replay_backoff;
     s->replay_backoff = s->replay_backoff < 1024 ? s->replay_backoff * 2 : 1024;
-    HIPCHK(hipMemcpyAsync(d_xu, s->d_snap_xu, bx, hipMemcpyDeviceToDevice, st));
+    const size_t bx = (size_t)B * s->traj * sizeof(float), bl = (size_t)B * s->vecp * sizeof(float), bb = (size_t)B * sizeof(float);
+    bf.xu = s->pend.d_xu; bf.x_s = s->pend.d_xs; bf.ref = s->pend.d_ref;
+    HIPCHK(hipMemcpyAsync(s->pend.d_xu, s->d_snap_xu, bx, hipMemcpyDeviceToDevice, st));
     HIPCHK(hipMemcpyAsync(bf.lambda, s->d_snap_lambda, bl, hipMemcpyDeviceToDevice, st));
     HIPCHK(hipMemcpyAsync(bf.rho, s->d_snap_rho, bb, hipMemcpyDeviceToDevice, st));
     HIPCHK(hipMemcpyAsync(bf.drho, s->d_snap_rho + B, bb, hipMemcpyDeviceToDevice, st));
-    return enqueue_solve<M>(s, dt, st, iters, true);   // (counted in n_replays, not in n_periter: that one counts solves that never ran speculatively)
+    return enqueue_solve<M>(s, s->pend.dt, st, iters, true);   // (counted in n_replays, not in n_periter: that one counts solves that never ran speculatively)
+}
+static int settle(GatoSolver* s)
+{
+    if (!s->pend.active) return GATO_OK;
+    return s->plant == GATO_PLANT_INDY7 ? settle_impl<Indy7>(s) : settle_impl<Iiwa14>(s);
 }
 
-static int solve_dispatch(GatoSolver* s, float* d_xu, float dt, const float* d_xs, const float* d_ref, hipStream_t st, bool async_only = false)
+static int solve_dispatch(GatoSolver* s, float* d_xu, float dt, const float* d_xs, const float* d_ref, hipStream_t st, bool async_only = false, bool lazy_ok = false)
 {
-    return s->plant == GATO_PLANT_INDY7 ? solve_impl<Indy7>(s, d_xu, dt, d_xs, d_ref, st, async_only) : solve_impl<Iiwa14>(s, d_xu, dt, d_xs, d_ref, st, async_only);
+    int rc = settle(s);   // a pending solve's verdict (and replay) before the next one starts from its results
+    if (rc != GATO_OK) return rc;
+    return s->plant == GATO_PLANT_INDY7 ? solve_impl<Indy7>(s, d_xu, dt, d_xs, d_ref, st, async_only, lazy_ok) : solve_impl<Iiwa14>(s, d_xu, dt, d_xs, d_ref, st, async_only, lazy_ok);
 }
 
 static void collect_profile(GatoSolver* s)
@@ -1063,7 +1141,9 @@ extern "C" int gato_solve_device(GatoSolver* s, float* d_xu, float dt, const flo
 {
     if (!s || !d_xu || !d_xs || !d_ref) return fail(GATO_ERR_INVALID, "null argument");
     GUARD(s);
-    return solve_dispatch(s, d_xu, dt, d_xs, d_ref, (hipStream_t)stream);
+    // a sharded solve in the deferred count mode returns with its verdict PENDING (taken by the next entry point on this handle, settle()); profiling
+    // wants the stage events of a finished solve
+    return solve_dispatch(s, d_xu, dt, d_xs, d_ref, (hipStream_t)stream, false, !s->profiling);
 }
 
 extern "C" int gato_solve(GatoSolver* s, float* xu, float dt, const float* x_s, const float* ref, double* sqp_time_us)
@@ -1120,6 +1200,10 @@ extern "C" int gato_solve(GatoSolver* s, float* xu, float dt, const float* x_s, 
 // ---- statistics -------------------------------------------------------------------------------------------------------
 static int sync_last(GatoSolver* s)
 {
+    {   // a deferred sharded solve whose verdict is still out: take it (and replay, if the rule fired) before anything looks at the state
+        const int rc = settle(s);
+        if (rc != GATO_OK) return rc;
+    }
     // a solve enqueued on the caller's stream (gato_solve_device) may still be in flight: everything that reads or overwrites solver
     // state from the host waits for it first
     if (s->last_stream_valid) HIPCHK(hipStreamSynchronize(s->last_stream));
@@ -1252,6 +1336,10 @@ extern "C" int gato_reset_async(GatoSolver* s, int dual, int rho, void* stream)
     GUARD(s);
     hipStream_t st = (hipStream_t)stream;
     if (!dual && !rho) return GATO_OK;
+    {
+        const int rc = settle(s);   // the reset must come behind a pending solve's replay, not between its speculative run and the replay
+        if (rc != GATO_OK) return rc;
+    }
     // one launch for both
     const uint32_t n = dual ? (uint32_t)((size_t)s->B * s->vecp) : 0u;
     size_t blocks = ((size_t)n / 4 + 255) / 256;
@@ -1266,6 +1354,10 @@ extern "C" int gato_copy_final_merit_device(GatoSolver* s, float* d_out, void* s
 {
     if (!s || !d_out) return fail(GATO_ERR_INVALID, "null argument");
     GUARD(s);
+    {
+        const int rc = settle(s);   // the merits of the solve that stands
+        if (rc != GATO_OK) return rc;
+    }
     HIPCHK(hipMemcpyAsync(d_out, s->bf.merit_cur, s->B * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return GATO_OK;
 }

@@ -236,10 +236,19 @@ int gato_comm_destroy(GatoSolver* s);
 int gato_gather_results(GatoSolver* s, const gato_real* d_local, gato_real* d_all, uint64_t count, void* stream);
 /* How a sharded solve learns the whole batch's solved count (the exit rule of bsqp.cuh:165 is the only coupling between the shards):
  *   GATO_COUNT_DEFERRED (default)   the solve runs speculatively as if the rule never fired, every rank counting its own rows; ONE
- *       all-reduce of the [max_sqp_iters] count vector at its end, then the host looks at it (gato_solve_device therefore returns only when
- *       a sharded solve has finished).  Only if some iteration's whole-batch count reached batch x solve_ratio -- never on workloads whose
- *       trajectories do not converge -- the snapshot taken at the start (xu, lambda, rho, drho) is restored and the solve re-run with the
- *       per-iteration reduction: the results are those of the unsharded solver either way, bit for bit.
+ *       all-reduce of the [max_sqp_iters] count vector at its end, published to the host by the device itself (pinned memory, no copy engine).
+ *       Only if some iteration's whole-batch count reached batch x solve_ratio -- never on workloads whose trajectories do not converge -- the
+ *       snapshot taken at the start (xu, lambda, rho, drho) is restored and the solve re-run with the per-iteration reduction: the results are
+ *       those of the unsharded solver either way, bit for bit.
+ *       WHEN the host looks (round 6): gato_solve_device returns as soon as the solve, the reduction and the publication are enqueued, with the
+ *       verdict PENDING; it is taken -- the one host wait of a sharded solve, and the replay if the rule fired -- by the NEXT entry point on the
+ *       handle that reads or changes the solver's state or the solve's results: gato_solve_device, gato_reset_async, gato_copy_final_merit_device,
+ *       gato_synchronize, every gato_get_* / gato_set_* / gato_reset_* / gato_debug_*, gato_comm_*, gato_destroy.  Until then d_xu holds the speculative
+ *       iterates: a caller that reads d_xu with its OWN kernels or copies calls one of those first (gato_synchronize also drains the stream;
+ *       gato_copy_final_merit_device only takes the verdict).  gato_gather_results does NOT take it -- it touches nothing of the solver's -- which
+ *       is what the split is for: between gato_solve_device and the next entry point the host is free, and bench.py enqueues the PREVIOUS solve's
+ *       gather there, with the device busy (the verdict taken inside gato_solve_device left the device idle for every host call between two
+ *       solves: 87 us per 1.7 ms solve at C4, profiles/r06_scaling_prediction.json).  gato_solve and gato_mpc_step take the verdict themselves.
  *   GATO_COUNT_PER_ITERATION        one 4-byte all-reduce between the PCG launch and the step launch of every SQP iteration, no host wait
  *       (round 3's form; also what a hipGraph capture of a sharded solve uses).
  * A solve on a stream that is being CAPTURED (gato_solve_device under hipStreamBeginCapture) always counts per iteration: the deferred form's

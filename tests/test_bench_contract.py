@@ -168,8 +168,8 @@ def test_rows_of_another_rank_through_the_one_rank_communicator(extra):
     assert abs(d["value"] - B * 10 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
     mg = d["multi_gpu"]
     assert "ncclAllGather" in mg["collective"] and mg["solved_count"].startswith("deferred") and "one_rank_comm" in mg
-    # every solve of the run (warm-up, timed, the no-gather loop, the profiled one) ran speculatively, none was replayed, none counted per iteration
-    assert mg["solves_by_count_form"]["speculative"] >= 4 + 1 + 2 + 1 and mg["solves_by_count_form"]["replayed"] == 0 and mg["solves_by_count_form"]["per_iteration"] == 0
+    # every solve of the run so far (warm-up, timed, the no-gather loop) ran speculatively, none was replayed, none counted per iteration
+    assert mg["solves_by_count_form"]["speculative"] == 4 + 1 + 2 and mg["solves_by_count_form"]["replayed"] == 0 and mg["solves_by_count_form"]["per_iteration"] == 0
     assert mg["gather_ms"]["max_over_ranks"] > 0 and mg["solve_ms_without_gather"] > 0
     # the same rows without the communicator: the same iterates' statistics (the sharded path does not change a trajectory), and the plain loop is not slower
     r2 = _run("--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--as-rank", "3", "--of", "8", *args)
