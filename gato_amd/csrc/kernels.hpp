@@ -1426,6 +1426,11 @@ template<int PARTS = 4> GATO_DEV float block_sum(float v, float* part, unsigned 
     v = wave_sum(v);
     if ((tx & 63) == 0) part[tx >> 6] = v;
     __syncthreads();
+#ifdef GATO_EXP_PARTS2
+    // EXPERIMENT (round 6, C2 only: a workgroup of TWO wavefronts): the two partials by one 8-byte read and one add instead of a 16-byte read and
+    // (a.x + a.y) + (0 + 0) -- two dependent adds fewer on the chain behind each reduction barrier (make libgato_hip_exp.so; profiles/r06_c2_chain.txt)
+    if constexpr (PARTS == 1) { const real2 a2 = reinterpret_cast<const real2*>(part)[0]; return a2.x + a2.y; }
+#endif
     const real4 a = reinterpret_cast<const real4*>(part)[0];
     float r = (a.x + a.y) + (a.z + a.w);
     if constexpr (PARTS == 1) return r;

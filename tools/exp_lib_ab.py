@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""A / B of two builds of the fp32 library on the headline workload: same bits (sha256 of the iterates, duals and PCG counts of a 10-iteration C2 solve)
+and the driver-style bench value (bench.py --steps 200, best and median of `--runs`).  The experimental build is loaded through GATO_HIP_LIB.
+
+    make -C gato_amd/csrc libgato_hip_exp.so EXPFLAGS=-DGATO_EXP_PARTS2
+    python tools/exp_lib_ab.py --exp gato_amd/csrc/libgato_hip_exp.so [--runs 5]
+"""
+import argparse
+import hashlib
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+DIGEST = r'''
+import hashlib, json, sys
+sys.path.insert(0, %r)
+import numpy as np
+from gato_amd._lib import NativeSolver
+from gato_amd.bsqp.config import DEFAULT_SOLVER_PARAMS
+from gato_amd.bsqp.workloads import fig8_problem
+pr = fig8_problem("indy7", 32, 1024)
+s = NativeSolver("indy7", 32, 1024, dt=0.01, **dict(DEFAULT_SOLVER_PARAMS, max_sqp_iters=10))
+r = s.solve(pr["xu"], 0.01, pr["x_s"], pr["ref"])
+h = hashlib.sha256()
+for a in (r["XU"], s.read("lambda"), r["pcg_iters_all"], r["final_merit"], r["ls_step_size"]):
+    h.update(np.ascontiguousarray(a).tobytes())
+print(json.dumps({"digest": h.hexdigest()[:16], "sum_max_pcg": int(r["pcg_iters_all"].max(axis=1).sum())}))
+''' % ROOT
+
+
+def run(env, args):
+    r = subprocess.run(args, cwd=ROOT, capture_output=True, text=True, env=env, timeout=900)
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    if r.returncode != 0 or not lines:
+        raise RuntimeError(r.stderr[-1500:])
+    return json.loads(lines[-1])
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--exp", required=True)
+    ap.add_argument("--runs", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    a = ap.parse_args()
+    out = {}
+    for name, lib in (("base", None), ("exp", os.path.abspath(a.exp))):
+        env = dict(os.environ)
+        if lib:
+            env["GATO_HIP_LIB"] = lib
+        d = run(env, [sys.executable, "-c", DIGEST])
+        vals, ms, pcg = [], [], []
+        for _ in range(a.runs):
+            b = run(env, [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", str(a.steps), "--warmup", "10", "--no-cpu-baseline"])
+            vals.append(b["value"]); ms.append(b["ms_per_step"]); pcg.append(b["roofline"]["avg_launch_us"])
+        out[name] = {"library": lib or "gato_amd/csrc/libgato_hip.so", **d, "bench_values": vals, "ms_per_solve": ms, "pcg_launch_us": pcg,
+                     "best_value": max(vals), "median_value": sorted(vals)[len(vals) // 2]}
+        print(name, json.dumps(out[name]), flush=True)
+    out["same_bits"] = out["base"]["digest"] == out["exp"]["digest"]
+    out["median_gain"] = out["exp"]["median_value"] / out["base"]["median_value"] - 1.0
+    out["best_gain"] = out["exp"]["best_value"] / out["base"]["best_value"] - 1.0
+    print(json.dumps({"same_bits": out["same_bits"], "median_gain": out["median_gain"], "best_gain": out["best_gain"]}))
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    json.dump(out, open(os.path.join(ROOT, "gpurun_out", "r06_c2_chain.json"), "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
