@@ -1421,16 +1421,17 @@ GATO_DEV float wave_sum(float v)
 // PARTS = 16-byte groups that can hold a wavefront's partial (<= 4 PARTS wavefronts in the workgroup): the skipped ones are exact
 // zeros, so every PARTS gives the same bits.
 // tx: the thread's index inside the group of wavefronts that sums (the workgroup)
-template<int PARTS = 4> GATO_DEV float block_sum(float v, float* part, unsigned tx = threadIdx.x)
+// two: the summing group is exactly TWO wavefronts (wavefront-uniform; C2's fused kernel): their partials by one 8-byte read and one add.  The other
+// slots are exact zeros, so (a.x + a.y) + (0 + 0) has the same bits -- two dependent adds and half the read off the chain behind every reduction barrier
+// (round 6: +0.7 % on the headline, five runs each, iterates bit-identical: profiles/r06_c2_chain.json)
+template<int PARTS = 4> GATO_DEV float block_sum(float v, float* part, unsigned tx = threadIdx.x, bool two = false)
 {
     v = wave_sum(v);
     if ((tx & 63) == 0) part[tx >> 6] = v;
     __syncthreads();
-#ifdef GATO_EXP_PARTS2
-    // EXPERIMENT (round 6, C2 only: a workgroup of TWO wavefronts): the two partials by one 8-byte read and one add instead of a 16-byte read and
-    // (a.x + a.y) + (0 + 0) -- two dependent adds fewer on the chain behind each reduction barrier (make libgato_hip_exp.so; profiles/r06_c2_chain.txt)
-    if constexpr (PARTS == 1) { const real2 a2 = reinterpret_cast<const real2*>(part)[0]; return a2.x + a2.y; }
-#endif
+    if constexpr (PARTS == 1) {
+        if (two) { const real2 a2 = reinterpret_cast<const real2*>(part)[0]; return a2.x + a2.y; }
+    }
     const real4 a = reinterpret_cast<const real4*>(part)[0];
     float r = (a.x + a.y) + (a.z + a.w);
     if constexpr (PARTS == 1) return r;
@@ -2164,7 +2165,8 @@ GATO_DEV void pcgc_body(const Buffers& bf, int N, int B, int b, unsigned tx, uns
             pv[u] = zv[u];
             loc += rv[u] * zv[u];
         }
-        float rho = block_sum<PARTS>(loc, partA, tx);
+        const bool two = TT == 128;   // the workgroup is two wavefronts (N = 32 at three rows per thread): block_sum's short form
+        float rho = block_sum<PARTS>(loc, partA, tx, two);
         const bool entered = !(fabsf(rho) < abs_tol);
         if (entered) {
             const float rho_init = fabsf(rho);
@@ -2179,7 +2181,7 @@ GATO_DEV void pcgc_body(const Buffers& bf, int N, int B, int b, unsigned tx, uns
                     if (!have) acc[u] = 0.f;
                     loc += pv[u] * acc[u];
                 }
-                const float pAp = block_sum<PARTS>(loc, partB, tx);
+                const float pAp = block_sum<PARTS>(loc, partB, tx, two);
                 const float alpha = pcg_div(rho, pAp);
 #pragma unroll
                 for (int u = 0; u < RPT; u++) {
@@ -2195,7 +2197,7 @@ GATO_DEV void pcgc_body(const Buffers& bf, int N, int B, int b, unsigned tx, uns
                     zv[u] = have ? acc[u] : 0.f;
                     loc += rv[u] * zv[u];
                 }
-                const float rho_new = block_sum<PARTS>(loc, partA, tx);
+                const float rho_new = block_sum<PARTS>(loc, partA, tx, two);
                 if (fabsf(rho_new) < (abs_tol + eps * rho_init)) break;
                 const float beta = pcg_div(rho_new, rho);
                 rho = rho_new;
@@ -2521,230 +2523,6 @@ __global__ __launch_bounds__(MAXT, 2) void pcgs_kernel(Buffers bf, int N, int B,
         bf.st_pcg_iters[(size_t)sqp_iter * B + b] = (int32_t)iters;
         int conv = skip ? 1 : 0;
         if (iters == 0) { conv = 1; bf.converged[b] = 1; }  // bsqp.cuh:153-156 (kkt_tol is unused there)
-        if (conv) atomicAdd(&bf.num_solved_w[sqp_iter], 1u);
-    }
-}
-
-// ---- EXPERIMENT (round 6): the QUAD form of the symmetric-half-storage PCG kernel -------------------------------------------------------
-// pcgs_kernel splits a block row's work by ROLE (left-block threads carry 2 x the multiply-adds of main-block threads, the main role alone
-// gathers).  Here the four threads of block row k are a quad (h = row half, c = COLUMN PARITY): lane (k, h, c) holds the entries of rows
-// h HR .. of BOTH stored blocks (left_k, main_k) in the columns j = 2 jj + c -- the same 2 x HR x NX / 2 floats per matrix as a role thread --
-// and every lane carries the same work: HR x NX / 2 x 3 multiply-adds per product (left dot, main dot, transposed accumulate of left_k), the two
-// column parities of a row meet in one DPP quad_perm add, every lane owns (in duplicate over c) the vector entries of its rows and gathers them.
-// Column PARITY, not column half, because pcgs_kernel's row dots are (even-column chain) + (odd-column chain): lane c forms exactly one of the
-// two chains, so every sum associates as in pcgs_kernel and the two kernels give the SAME BITS (the reductions below rebuild wave_sum's tree of
-// the role layout).  No FOLD (reads the complete P^-1 that schur2_kernel leaves): the arbiter of "is the balanced form faster per iteration"
-// (profiles/r06_c3_quad.txt), not a product path.  T = 4 N threads, T / 64 in {4, 8} wavefronts.
-template<class M, int MAXT>
-__global__ __launch_bounds__(MAXT, 2) void pcgq_kernel(Buffers bf, int N, int B, uint32_t max_iters, int sqp_iter)
-{
-    constexpr int NQ = M::NQ, NX = 2 * NQ, HR = NX / 2, CH = NX / 2, BROW = 3 * NX * NX;
-    constexpr int NP = 4;                        // rows of BOTH P^-1 pieces parked in LDS
-    constexpr int PF4 = (NP * 2 * CH) / 4;       // as real4 chunks: floats in the order [row i][left | main][jj]
-    static_assert((NP * 2 * CH) % 4 == 0 && HR <= 8 && CH <= 8, "layout");
-    constexpr int VS = 16, PH = 8;               // LDS vectors: a block = [even entries (PH) | odd entries (PH)]; tbuf: [cols 0..HR-1 (PH) | cols HR.. (PH)]
-    constexpr int W = MAXT / 64;                 // wavefronts
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    if (bf.ctrl->done) return;
-    const int b = blockIdx.x, t = threadIdx.x, T = blockDim.x;
-    const int vecp = (N + 2) * NX, vecl = (N + 2) * VS;
-    float* va = lds;
-    float* vb = va + vecl;
-    float* partA = vb + vecl;                    // [2][8]: the wavefronts' left-part and main-part sums
-    float* partB = partA + 16;
-    float* tbuf = partB + 16;                    // [N + 1][2][VS]
-    real4* park = reinterpret_cast<real4*>(tbuf + (N + 1) * 2 * VS) + t;   // [PF4][T]
-    if (t < 32) partA[t] = 0.f;
-    const float abs_tol = 1e-6f;
-    uint32_t iters = 0;
-    const bool skip = bf.converged[b] != 0;
-    if (!skip) {
-        const float eps = bf.pcg_tol[b];
-        const int k = t >> 2, h = (t >> 1) & 1, c = t & 1;
-        const int r0 = k * NX + h * HR;
-        const float* gam = bf.gamma + (size_t)b * vecp;
-        float* lam = bf.lambda + (size_t)b * vecp;
-        float SL[HR][CH], SM[HR][CH], PL[HR - NP][CH], PM[HR - NP][CH];
-        {
-            const size_t boff = (size_t)b * N * BROW + (size_t)k * BROW + (size_t)h * HR * NX;
-            const float* Sg = bf.S + boff;
-            const float* Pg = bf.Pinv + boff;
-            float pk[NP * 2 * CH];
-#pragma unroll
-            for (int i = 0; i < HR; i++) {
-                float rowL[NX], rowM[NX];
-                load_vec<NX, 2>(rowL, Sg + i * NX);
-                load_vec<NX, 2>(rowM, Sg + NX * NX + i * NX);
-#pragma unroll
-                for (int jj = 0; jj < CH; jj++) { SL[i][jj] = c ? rowL[2 * jj + 1] : rowL[2 * jj]; SM[i][jj] = c ? rowM[2 * jj + 1] : rowM[2 * jj]; }
-                load_vec<NX, 2>(rowL, Pg + i * NX);
-                load_vec<NX, 2>(rowM, Pg + NX * NX + i * NX);
-#pragma unroll
-                for (int jj = 0; jj < CH; jj++) {
-                    const float l = c ? rowL[2 * jj + 1] : rowL[2 * jj], m = c ? rowM[2 * jj + 1] : rowM[2 * jj];
-                    if (i < NP) { pk[(i * 2 + 0) * CH + jj] = l; pk[(i * 2 + 1) * CH + jj] = m; }
-                    else { PL[i < NP ? 0 : i - NP][jj] = l; PM[i < NP ? 0 : i - NP][jj] = m; }
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < PF4; q++) park[q * T] = make_real4(pk[4 * q], pk[4 * q + 1], pk[4 * q + 2], pk[4 * q + 3]);
-        }
-        float xv[HR], rv[HR], pv[HR], gv[HR];
-#pragma unroll
-        for (int i = 0; i < HR; i++) { xv[i] = lam[NX + r0 + i]; gv[i] = gam[NX + r0 + i]; }
-        for (int i = t; i < VS; i += T) { va[i] = 0.f; vb[i] = 0.f; va[vecl - VS + i] = 0.f; vb[vecl - VS + i] = 0.f; }
-        for (int i = t; i < 2 * VS; i += T) tbuf[N * 2 * VS + i] = 0.f;
-        __syncthreads();   // the zeroed end blocks before anyone publishes
-        // lane (h, c) publishes the entries of its rows whose parity is c: entry rr of a block sits at (rr & 1) PH + (rr >> 1)
-        auto publish = [&](float* vec, const float* v) {
-            float* blk = vec + (k + 1) * VS + c * PH;
-#pragma unroll
-            for (int i = 0; i < HR; i++) {
-                const int rr0 = i, rr1 = HR + i;                 // the row inside the block for h = 0 / 1
-                const bool mine = (((h ? rr1 : rr0) & 1) == c);
-                if (mine) blk[(h ? rr1 : rr0) >> 1] = v[i];
-            }
-        };
-        const int own_t = ((k + 1) * 2) * VS + h * PH;           // this lane's rows in the transposed partials of block k + 1 (row half 0; + VS: half 1)
-        // the two sums of a product (left part, main part) in the association of pcgs_kernel's wave_sum over its role wavefronts: a role wavefront =
-        // two of this kernel's wavefronts, a 16-lane row there = two rows here
-        auto pair_sum = [&](float v) -> float {
-            v += dpp_get<0x4E>(v);    // the two row halves of a block row (every lane of the quad: the block row's sum)
-            v += dpp_get<0x141>(v);   // row_half_mirror: two block rows = a quad of the role layout
-            v += dpp_get<0x140>(v);   // row_mirror: four block rows = half a row of the role layout
-            const float a0 = lane_read(v, 0), a1 = lane_read(v, 16), a2 = lane_read(v, 32), a3 = lane_read(v, 48);
-            return (a2 + a3) + (a0 + a1);   // (role row 2w+1) + (role row 2w), each = its two halves in lane order
-        };
-        auto total = [&](const float* part) -> float {
-            const real4 l0 = reinterpret_cast<const real4*>(part)[0], l1 = reinterpret_cast<const real4*>(part)[1];
-            const real4 m0 = reinterpret_cast<const real4*>(part)[2], m1 = reinterpret_cast<const real4*>(part)[3];
-            if constexpr (W == 8) {
-                const float L0 = l0.y + l0.x, L1 = l0.w + l0.z, L2 = l1.y + l1.x, L3 = l1.w + l1.z;
-                const float M0 = m0.y + m0.x, M1 = m0.w + m0.z, M2 = m1.y + m1.x, M3 = m1.w + m1.z;
-                return ((L0 + L1) + (L2 + L3)) + ((M0 + M1) + (M2 + M3));
-            } else {
-                const float L0 = l0.y + l0.x, L1 = l0.w + l0.z, M0 = m0.y + m0.x, M1 = m0.w + m0.z;
-                return (L0 + L1) + (M0 + M1);
-            }
-        };
-        // out[i] = row r0 + i of Mx v; vo: the lane's own entries of v (registers); vec: the LDS copy of v; ISP: Mx = P^-1
-        auto matvec = [&](const float* vec, auto isp, float* out, const float* vo, float* part) -> float {
-            constexpr bool ISP = decltype(isp)::value;
-            float wl[PH], wm[PH], el[HR], em[HR], tp[CH];
-            load_vec<PH, 4>(wl, vec + k * VS + c * PH);          // block k - 1 of the padded vector, this lane's column parity
-            load_vec<PH, 4>(wm, vec + (k + 1) * VS + c * PH);
-#pragma unroll
-            for (int i = 0; i < HR; i++) { el[i] = 0.f; em[i] = 0.f; }
-#pragma unroll
-            for (int jj = 0; jj < CH; jj++) tp[jj] = 0.f;
-            if constexpr (ISP) {
-#pragma unroll
-                for (int q = 0; q < PF4; q++) {
-                    const real4 m4 = park[q * T];
-                    const float m[4] = {m4.x, m4.y, m4.z, m4.w};
-#pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        const int f = 4 * q + e, i = f / (2 * CH), blk = (f / CH) & 1, jj = f % CH;
-                        if (blk == 0) { el[i] = __builtin_fmaf(m[e], wl[jj], el[i]); tp[jj] = __builtin_fmaf(m[e], vo[i], tp[jj]); }
-                        else em[i] = __builtin_fmaf(m[e], wm[jj], em[i]);
-                    }
-                }
-#pragma unroll
-                for (int i = NP; i < HR; i++) {
-#pragma unroll
-                    for (int jj = 0; jj < CH; jj++) {
-                        el[i] = __builtin_fmaf(PL[i - NP][jj], wl[jj], el[i]);
-                        tp[jj] = __builtin_fmaf(PL[i - NP][jj], vo[i], tp[jj]);
-                        em[i] = __builtin_fmaf(PM[i - NP][jj], wm[jj], em[i]);
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < HR; i++) {
-#pragma unroll
-                    for (int jj = 0; jj < CH; jj++) {
-                        el[i] = __builtin_fmaf(SL[i][jj], wl[jj], el[i]);
-                        tp[jj] = __builtin_fmaf(SL[i][jj], vo[i], tp[jj]);
-                        em[i] = __builtin_fmaf(SM[i][jj], wm[jj], em[i]);
-                    }
-                }
-            }
-            // column j = 2 jj + c of the transposed partial of (block k, row half h)
-            {
-                float* tb = tbuf + (k * 2 + h) * VS;
-#pragma unroll
-                for (int jj = 0; jj < CH; jj++) {
-                    const int j0 = 2 * jj, j1 = 2 * jj + 1;
-                    tb[c ? (j1 < HR ? j1 : j1 - HR + PH) : (j0 < HR ? j0 : j0 - HR + PH)] = tp[jj];
-                }
-            }
-            float dl = 0.f, dm = 0.f;
-#pragma unroll
-            for (int i = 0; i < HR; i++) {
-                el[i] += dpp_get<0xB1>(el[i]);   // (even-column chain) + (odd-column chain): pcgs_kernel's a2.x + a2.y
-                em[i] += dpp_get<0xB1>(em[i]);
-                dl = __builtin_fmaf(el[i], vo[i], dl);
-                dm = __builtin_fmaf(em[i], vo[i], dm);
-            }
-            dl = 2.0f * dl;
-            dl = pair_sum(dl);
-            dm = pair_sum(dm);
-            if ((t & 63) == 0) { part[t >> 6] = dl; part[8 + (t >> 6)] = dm; }
-            __syncthreads();
-            float t0[PH], t1[PH];
-            load_vec<PH, 4>(t0, tbuf + own_t);
-            load_vec<PH, 4>(t1, tbuf + own_t + VS);
-#pragma unroll
-            for (int i = 0; i < HR; i++) out[i] = ((em[i] + el[i]) + t0[i]) + t1[i];
-            return total(part);
-        };
-        using yes = std::true_type;
-        using no = std::false_type;
-
-        publish(va, xv);
-        __syncthreads();
-        float acc[HR], zv[HR];
-        (void)matvec(va, no{}, acc, xv, partB);
-#pragma unroll
-        for (int i = 0; i < HR; i++) rv[i] = gv[i] - acc[i];
-        publish(vb, rv);
-        __syncthreads();
-        float rho = matvec(vb, yes{}, zv, rv, partA);
-#pragma unroll
-        for (int i = 0; i < HR; i++) pv[i] = zv[i];
-        if (!(fabsf(rho) < abs_tol)) {
-            const float rho_init = fabsf(rho);
-            for (uint32_t it = 0; it < max_iters; it++) {
-                iters++;
-                publish(va, pv);
-                __syncthreads();
-                const float pAp = matvec(va, no{}, acc, pv, partB);
-                const float alpha = pcg_div(rho, pAp);
-#pragma unroll
-                for (int i = 0; i < HR; i++) {
-                    xv[i] += alpha * pv[i];
-                    rv[i] -= alpha * acc[i];
-                }
-                publish(vb, rv);
-                __syncthreads();
-                const float rho_new = matvec(vb, yes{}, zv, rv, partA);
-                if (fabsf(rho_new) < (abs_tol + eps * rho_init)) break;
-                const float beta = pcg_div(rho_new, rho);
-                rho = rho_new;
-#pragma unroll
-                for (int i = 0; i < HR; i++) pv[i] = zv[i] + beta * pv[i];
-            }
-            if (c == 0) {
-#pragma unroll
-                for (int i = 0; i < HR; i++) lam[NX + r0 + i] = xv[i];
-            }
-        }
-    }
-    if (threadIdx.x == 0) {
-        bf.pcg_iters[b] = iters;
-        bf.st_pcg_iters[(size_t)sqp_iter * B + b] = (int32_t)iters;
-        int conv = skip ? 1 : 0;
-        if (iters == 0) { conv = 1; bf.converged[b] = 1; }
         if (conv) atomicAdd(&bf.num_solved_w[sqp_iter], 1u);
     }
 }

@@ -69,7 +69,6 @@ struct GatoSolver {
     // streaming pcg_kernel), whether it forms the stair off-diagonals itself (then schur2_kernel is not launched) and whether the
     // Schur complement is formed inside it.  Tuning overrides GATO_PCG_VARIANT / GATO_PCG_FOLD are read there, never in the solve loop.
     int pcg_choice, pcg_fold, pcg_fused, pcg_pair;
-    int pcg_quad = 0;   // EXPERIMENT (GATO_PCGS_QUAD=1): the quad form of the symmetric-storage kernel (pcgq_kernel, no fold) instead of pcgs_kernel
     int cus;   // compute units of the solver's device
     int pcg_rounds;   // > 1: the PCG workgroups are scheduled hardest-first (Buffers::order), see plan_pcg
     int32_t* d_order;
@@ -173,9 +172,9 @@ extern "C" int gato_dims(int plant, int N, int* nq, int* nx, int* nu, int* traj)
     return GATO_OK;
 }
 
+static int settle(GatoSolver* s);
 static int plan_pcg_dispatch(GatoSolver* s);
 static int sync_last(GatoSolver* s);
-static int settle(GatoSolver* s);
 static int create_impl(GatoSolver* s, int plant, int N, int B, const GatoParams* params)
 {
     s->plant = plant; s->N = N; s->B = B;
@@ -428,20 +427,10 @@ template<class M> static bool pcgs_grant(const GatoSolver* s)
     return grant_lds(reinterpret_cast<const void*>(&pcgs_kernel<M, 512, false>), pcgs_lds(s)) &&
            grant_lds(reinterpret_cast<const void*>(&pcgs_kernel<M, 512, true>), pcgs_lds(s));
 }
-static size_t pcgq_lds(const GatoSolver* s)
-{
-    const size_t T = 4 * (size_t)s->N, N = s->N, ch = s->nx / 2;
-    return ((size_t)2 * (N + 2) * 16 + 32 + (N + 1) * 2 * 16) * sizeof(float) + (4 * 2 * ch / 4) * T * sizeof(real4);
-}
 // fold: the kernel forms the stair off-diagonals itself (solve path); otherwise it reads the complete P^-1 (stage tests, GATO_PCG_FOLD=0)
 template<class M> static void launch_pcgs(GatoSolver* s, hipStream_t st, int sqp_iter, bool fold)
 {
     const int T = 4 * s->N;
-    if (s->pcg_quad) {
-        if (T == 256) hipLaunchKernelGGL((pcgq_kernel<M, 256>), dim3(s->B), dim3(T), pcgq_lds(s), st, s->bf, s->N, s->B, s->p.max_pcg_iters, sqp_iter);
-        else hipLaunchKernelGGL((pcgq_kernel<M, 512>), dim3(s->B), dim3(T), pcgq_lds(s), st, s->bf, s->N, s->B, s->p.max_pcg_iters, sqp_iter);
-        return;
-    }
     if (T <= 256) {
         if (fold) hipLaunchKernelGGL((pcgs_kernel<M, 256, true>), dim3(s->B), dim3(T), pcgs_lds(s), st, s->bf, s->N, s->B, s->p.max_pcg_iters, sqp_iter);
         else hipLaunchKernelGGL((pcgs_kernel<M, 256, false>), dim3(s->B), dim3(T), pcgs_lds(s), st, s->bf, s->N, s->B, s->p.max_pcg_iters, sqp_iter);
@@ -480,15 +469,6 @@ template<class M> static int plan_pcg(GatoSolver* s)
             case 1: fold = pcgc_grant_fold<M, 6>(s); break;
             case 4: fold = pcgc_grant_fold<M, 1, 4>(s); break;
             case 7: break;   // granted with the kernel (pcgs_grant)
-        }
-    }
-    {
-        const char* qe = getenv("GATO_PCGS_QUAD");
-        s->pcg_quad = 0;
-        if (qe && atoi(qe) != 0 && choice == 7 && (4 * s->N == 256 || 4 * s->N == 512) &&
-            grant_lds(4 * s->N == 256 ? reinterpret_cast<const void*>(&pcgq_kernel<M, 256>) : reinterpret_cast<const void*>(&pcgq_kernel<M, 512>), pcgq_lds(s))) {
-            s->pcg_quad = 1;
-            fold = false;   // the experiment reads the complete P^-1 (schur2_kernel runs)
         }
     }
     s->pcg_fold = fold ? 1 : 0;

@@ -160,10 +160,10 @@ def test_direct_solver_lds_grant_is_per_handle_and_checked(lib):
 
 def test_the_experiment_patches_still_apply():
     """tools/microbench/*.patch keep code that was measured and taken out of the product (the persistent SQP loop, the per-wavefront phase trace, the split
-    gather of pcgs_kernel): evidence only as long as they apply to the sources they describe.  (pcgc_dual_role.patch is round 4's, against round 4's sources.)"""
+    gather of pcgs_kernel, round 6's quad form of it): evidence only as long as they apply to the sources they describe.  (pcgc_dual_role.patch is round 4's, against round 4's sources.)"""
     import shutil
     if shutil.which("patch") is None:
         pytest.skip("no `patch` on this host")
-    for name in ("sqp_pair.patch", "pcg_phase_trace.patch", "pcgs_split.patch", "pcgs_padded_partials.patch"):
+    for name in ("sqp_pair.patch", "pcg_phase_trace.patch", "pcgs_split.patch", "pcgs_padded_partials.patch", "pcgs_quad.patch"):
         r = subprocess.run(["patch", "-p1", "--dry-run", "--batch", "-i", os.path.join(ROOT, "tools", "microbench", name)], cwd=ROOT, capture_output=True, text=True)
         assert r.returncode == 0, (name, r.stdout[-800:])

@@ -370,8 +370,9 @@ def test_first_iteration_decisions_on_every_shard_of_c4(shard):
 # 87 % / 96 % of max|dz|).  Conditioning cannot touch the float64 build: the SAME kernel sources compiled with double (libgato_hip_f64.so) against
 # the float64 oracle from IDENTICAL inputs leave cond x 1e-16 ~ 1e-7.  This is the check that says "the HIP formulas ARE the oracle's" on every
 # trajectory / block of all 8 sweep shards at full size (iiwa14 N = 64, B = 512, per-trajectory rho over nine decades):
-#   merit of the warm start, KKT blocks, (Q + rho I)^-1, R^-1, S, the 8 merits from the oracle's dz        <= 1e-9  (per buffer / per trajectory)
-#   gamma (per trajectory), P^-1 (EVERY (trajectory, knot) block, main and stair), dz from the oracle's lambda (per trajectory)   <= 1e-6
+#   merit of the warm start, KKT blocks, (Q + rho I)^-1, R^-1, S (also block by block), the 8 merits from the oracle's dz   <= 1e-12 (measured <= 1.7e-14)
+#   gamma and dz from the oracle's lambda, per trajectory; the KKT residuals                                              <= 1e-10 (measured <= 1e-12)
+#   P^-1, EVERY (trajectory, knot) block, main and stair                                                                  <= 1e-8  (measured <= 1e-9)
 #   step, rho, drho, merit_cur and the new iterate from the oracle's merit table                            bit for bit
 # schur_linsys.cuh:121-128 (gamma), :150-164 + :213-260 (P^-1 and its stair blocks), :316-431 (dz).
 def _blocks3(a, b, nx):
@@ -444,10 +445,12 @@ def test_float64_build_stage_by_stage_on_every_sweep_shard(shard):
     m["steps_taken"], m["distinct_steps"] = int((step > 0).sum()), int(len(np.unique(step)))
     _report(test="stagewise_shard_f64", case="C5", shard=shard, plant=plant, N=N, B=B, rho_min=float(pr["rho"].min()), rho_max=float(pr["rho"].max()),
              **{("err_" + k) if k not in ("steps_taken", "distinct_steps") else k: v for k, v in m.items()})
+    # measured on MI355X (profiles/r06_parity_full_size.json): everything well-conditioned <= 1.7e-14, gamma <= 8e-13, dz <= 1e-12, P^-1's worst block <= 1e-9
     for name in ("merit0", "A", "B", "c", "Q", "q", "R", "r", "Qinv", "Rinv", "S", "S_worst_block", "merit8"):
-        assert m[name] <= 1e-9, (name, m)
-    for name in ("gamma_rows", "Pinv_worst_block", "dz_rows", "q_res", "r_res"):
-        assert m[name] <= 1e-6, (name, m)
+        assert m[name] <= 1e-12, (name, m)
+    for name in ("gamma_rows", "dz_rows", "q_res", "r_res"):
+        assert m[name] <= 1e-10, (name, m)
+    assert m["Pinv_worst_block"] <= 1e-8, m      # cond(theta + rho I) ~ 4e9 x 2e-16, on the worst of 512 x 64 x 3 blocks
     for name in ("step", "rho", "drho", "merit_cur"):
         np.testing.assert_array_equal(nat.read(name), orc.buf(name), err_msg=name)
     np.testing.assert_array_equal(xg, xo)

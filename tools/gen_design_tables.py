@@ -55,34 +55,45 @@ def bench_block(tag):
 
 
 def heatmap_block():
-    """the reference's MPC solve-time heat-map next to this library's (profiles/r03_mpc_heatmap_*.json, tools/mpc_heatmap.py)"""
+    """the reference's MPC solve-time heat-map next to this library's (profiles/r06_mpc_heatmap_{pcg,direct}.json, tools/mpc_heatmap.py --solve-wall).
+    THREE figures per cell: the host wall clock around the solve alone, device-synchronised on both sides -- the reference's own `sqp_time_us`
+    (bsqp.cuh:109,185), which is what its published heat-map shows, and therefore the column compared with it --, the device time between hipEvents
+    around the solve's launches, and the host wall clock of the whole session step."""
     cells, pub = {}, {}
-    for f in ("short_pcg", "long_pcg", "long_direct"):
-        path = os.path.join(ROOT, "profiles", "r04_mpc_heatmap_%s.json" % f)   # the latest round that measured it
-        if not os.path.exists(path):
-            path = os.path.join(ROOT, "profiles", "r03_mpc_heatmap_%s.json" % f)
-        for c in json.load(open(path)):
+    for f in ("pcg", "direct"):
+        for c in json.load(open(os.path.join(ROOT, "profiles", "r06_mpc_heatmap_%s.json" % f))):
             cells[(c["knots"], c["linear_solver"], c["batch"])] = c
             if c.get("published_ms") is not None:
                 pub[(c["knots"], c["batch"])] = c["published_ms"]
     batches = sorted({k[2] for k in cells})
-    rows = ["| N \\\\ batch | " + " | ".join(str(b) for b in batches) + " |", "|" + "---|" * (len(batches) + 1)]
-    ahead = {"pcg": 0, "best": 0}
+    rows = ["| N \\ batch | " + " | ".join(str(b) for b in batches) + " |", "|" + "---|" * (len(batches) + 1)]
+    ahead = {("pcg", "solve_wall_mean_ms"): 0, ("pcg", "mean_ms"): 0, ("best", "solve_wall_mean_ms"): 0, ("best", "mean_ms"): 0, ("pcg", "step_wall_mean_ms"): 0, ("best", "step_wall_mean_ms"): 0}
+    lost = []
     for N in sorted({k[0] for k in cells}):
         for ls in ("pcg", "direct"):
             if (N, ls, batches[0]) not in cells:
                 continue
-            rows.append("| %d: this library, %s (ms) | " % (N, "PCG" if ls == "pcg" else "**direct**") +
-                        " | ".join("%.3f" % cells[(N, ls, b)]["mean_ms"] if (N, ls, b) in cells else "–" for b in batches) + " |")
+            name = "PCG" if ls == "pcg" else "**direct**"
+            rows.append("| %d: %s, solve wall = `sqp_time_us` (ms) | " % (N, name) +
+                        " | ".join(("**%.3f**" if (N, b) in pub and cells[(N, ls, b)]["solve_wall_mean_ms"] >= pub[(N, b)] else "%.3f") % cells[(N, ls, b)]["solve_wall_mean_ms"]
+                                   if (N, ls, b) in cells else "–" for b in batches) + " |")
+            rows.append("| %d: %s, device events (ms) | " % (N, name) + " | ".join("%.3f" % cells[(N, ls, b)]["mean_ms"] if (N, ls, b) in cells else "–" for b in batches) + " |")
+        rows.append("| %d: whole session step, host wall, PCG (ms) | " % N + " | ".join("%.3f" % cells[(N, "pcg", b)]["step_wall_mean_ms"] for b in batches) + " |")
         rows.append("| %d: reference, published (ms) | " % N + " | ".join("%.2f" % pub[(N, b)] if (N, b) in pub else "–" for b in batches) + " |")
         for b in batches:
-            if (N, b) in pub:
-                ahead["pcg"] += cells[(N, "pcg", b)]["mean_ms"] < pub[(N, b)]
-                ahead["best"] += min(cells[(N, ls, b)]["mean_ms"] for ls in ("pcg", "direct") if (N, ls, b) in cells) < pub[(N, b)]
-    w = {(N, b): cells[(N, "pcg", b)]["step_wall_mean_ms"] for (N, ls, b) in cells if ls == "pcg"}
-    tail = ("\nBy the device time of the solve, %d of the %d published cells are faster here with PCG and %d with the better of PCG and the direct mode; "
-            "host wall time of the whole session step (`step_wall_mean_ms`): %.2f ms at N = 32, B = 1, %.2f ms at B = 256.\n"
-            % (ahead["pcg"], len(pub), ahead["best"], w[(32, 1)], w[(32, 256)]))
+            if (N, b) not in pub:
+                continue
+            for key in ("solve_wall_mean_ms", "mean_ms", "step_wall_mean_ms"):
+                ahead[("pcg", key)] += cells[(N, "pcg", b)][key] < pub[(N, b)]
+                ahead[("best", key)] += min(cells[(N, ls, b)][key] for ls in ("pcg", "direct") if (N, ls, b) in cells) < pub[(N, b)]
+            if cells[(N, "pcg", b)]["solve_wall_mean_ms"] >= pub[(N, b)]:
+                lost.append("N = %d B = %d (%.3f vs %.2f)" % (N, b, cells[(N, "pcg", b)]["solve_wall_mean_ms"], pub[(N, b)]))
+    n = len(pub)
+    tail = ("\nBy the reference's own metric (host wall clock of the solve, bold = not ahead of the published cell): **%d of the %d published cells are faster here with PCG, "
+            "%d with the better of PCG and the direct mode**; by device time %d / %d; by the wall clock of the WHOLE session step (plant, prepare, solve, selection, read-back) "
+            "%d / %d.  PCG cells not ahead: %s.\n"
+            % (ahead[("pcg", "solve_wall_mean_ms")], n, ahead[("best", "solve_wall_mean_ms")], ahead[("pcg", "mean_ms")], ahead[("best", "mean_ms")],
+               ahead[("pcg", "step_wall_mean_ms")], ahead[("best", "step_wall_mean_ms")], "; ".join(lost) if lost else "none"))
     return "\n".join(rows) + "\n" + tail
 
 
