@@ -1421,16 +1421,18 @@ GATO_DEV float wave_sum(float v)
 // PARTS = 16-byte groups that can hold a wavefront's partial (<= 4 PARTS wavefronts in the workgroup): the skipped ones are exact
 // zeros, so every PARTS gives the same bits.
 // tx: the thread's index inside the group of wavefronts that sums (the workgroup)
-// two: the summing group is exactly TWO wavefronts (wavefront-uniform; C2's fused kernel): their partials by one 8-byte read and one add.  The other
-// slots are exact zeros, so (a.x + a.y) + (0 + 0) has the same bits -- two dependent adds and half the read off the chain behind every reduction barrier
-// (round 6: +0.7 % on the headline, five runs each, iterates bit-identical: profiles/r06_c2_chain.json)
-template<int PARTS = 4> GATO_DEV float block_sum(float v, float* part, unsigned tx = threadIdx.x, bool two = false)
+// TWO: the summing group is exactly two wavefronts (C2's fused kernel, instantiated with MAXT = 128): their partials by one 8-byte read and one add.
+// The other slots are exact zeros, so (a.x + a.y) + (0 + 0) has the same bits -- two dependent adds and half the read off the chain behind every
+// reduction barrier.  A COMPILE-TIME switch: the same thing behind a wavefront-uniform run-time branch measured 0.75 % SLOWER than not having it (the
+// branch sits on that same chain), the instantiation +0.8 % (profiles/r06_c2_two_form_abc.json: three builds round-robin on one box, same bits)
+template<int PARTS = 4, bool TWO = false> GATO_DEV float block_sum(float v, float* part, unsigned tx = threadIdx.x)
 {
     v = wave_sum(v);
     if ((tx & 63) == 0) part[tx >> 6] = v;
     __syncthreads();
-    if constexpr (PARTS == 1) {
-        if (two) { const real2 a2 = reinterpret_cast<const real2*>(part)[0]; return a2.x + a2.y; }
+    if constexpr (TWO) {
+        const real2 a2 = reinterpret_cast<const real2*>(part)[0];
+        return a2.x + a2.y;
     }
     const real4 a = reinterpret_cast<const real4*>(part)[0];
     float r = (a.x + a.y) + (a.z + a.w);
@@ -1840,6 +1842,7 @@ GATO_DEV void pcgc_body(const Buffers& bf, int N, int B, int b, unsigned tx, uns
 {
     constexpr int NQ = M::NQ, NX = 2 * NQ, BR = 3 * NX, BROW = 3 * NX * NX;
     constexpr int PARTS = (FUSE || MAXT <= 256) ? 1 : (MAXT <= 512 ? 2 : 4);  // FUSE is only launched with <= 256 threads
+    constexpr bool TWO = MAXT == 128 && !PAIR;   // launched with exactly 128 threads (solver.hip: launch_pcg_fused at N = 32): block_sum's two-wavefront form
     static_assert(!PAIR || (FUSE && FOLD), "the pair form exists for the fused kernel");
     constexpr int LA2 = (NX % 4 == 0) ? 4 : 2;  // alignment (floats) of an nx-float row in the LDS buffers
     static_assert(NX % RPT == 0, "rows of one thread must share a block row");
@@ -2165,8 +2168,7 @@ GATO_DEV void pcgc_body(const Buffers& bf, int N, int B, int b, unsigned tx, uns
             pv[u] = zv[u];
             loc += rv[u] * zv[u];
         }
-        const bool two = TT == 128;   // the workgroup is two wavefronts (N = 32 at three rows per thread): block_sum's short form
-        float rho = block_sum<PARTS>(loc, partA, tx, two);
+        float rho = block_sum<PARTS, TWO>(loc, partA, tx);
         const bool entered = !(fabsf(rho) < abs_tol);
         if (entered) {
             const float rho_init = fabsf(rho);
@@ -2181,7 +2183,7 @@ GATO_DEV void pcgc_body(const Buffers& bf, int N, int B, int b, unsigned tx, uns
                     if (!have) acc[u] = 0.f;
                     loc += pv[u] * acc[u];
                 }
-                const float pAp = block_sum<PARTS>(loc, partB, tx, two);
+                const float pAp = block_sum<PARTS, TWO>(loc, partB, tx);
                 const float alpha = pcg_div(rho, pAp);
 #pragma unroll
                 for (int u = 0; u < RPT; u++) {
@@ -2197,7 +2199,7 @@ GATO_DEV void pcgc_body(const Buffers& bf, int N, int B, int b, unsigned tx, uns
                     zv[u] = have ? acc[u] : 0.f;
                     loc += rv[u] * zv[u];
                 }
-                const float rho_new = block_sum<PARTS>(loc, partA, tx, two);
+                const float rho_new = block_sum<PARTS, TWO>(loc, partA, tx);
                 if (fabsf(rho_new) < (abs_tol + eps * rho_init)) break;
                 const float beta = pcg_div(rho_new, rho);
                 rho = rho_new;

@@ -478,7 +478,8 @@ template<class M> static int plan_pcg(GatoSolver* s)
     if constexpr (NX == 12) {
         fused = s->fuse_schur && fold && choice == 2 && PcgcShape<NX, 3, 0>::threads(s->N * s->nx) <= 256;
         if (fused) fused = grant_lds(reinterpret_cast<const void*>(&pcgc_kernel<M, 3, 256, true, true>), pcg_fused_lds<M>(s)) &&
-                           grant_lds(reinterpret_cast<const void*>(&pcgc_kernel<M, 3, 256, true, true, false, true>), pcg_fused_lds<M>(s));
+                           grant_lds(reinterpret_cast<const void*>(&pcgc_kernel<M, 3, 256, true, true, false, true>), pcg_fused_lds<M>(s)) &&
+                           grant_lds(reinterpret_cast<const void*>(&pcgc_kernel<M, 3, 128, true, true, false, true>), pcg_fused_lds<M>(s));
     }
     s->pcg_fused = fused ? 1 : 0;
     // Pair form of the fused kernel: two lanes per row group (twice the threads, half of the columns each; same bits).  A PCG iteration
@@ -563,7 +564,10 @@ template<class M> static void launch_pcg_fused(GatoSolver* s, hipStream_t st, fl
                 hipLaunchKernelGGL((pcgc_kernel<M, 3, 256, true, true, true>), dim3(s->B), dim3(2 * T), pcg_fused_lds<M>(s), st, s->bf, s->N, s->B,
                                    s->p.max_pcg_iters, sqp_iter, 0, dt);
         } else {
-            if (full)
+            if (full && T == 128)   // N = 32 (C2): exactly two wavefronts -- the instantiation whose reductions read two partials, not four (block_sum<.., TWO>)
+                hipLaunchKernelGGL((pcgc_kernel<M, 3, 128, true, true, false, true>), dim3(s->B), dim3(T), pcg_fused_lds<M>(s), st, s->bf, s->N, s->B,
+                                   s->p.max_pcg_iters, sqp_iter, 0, dt);
+            else if (full)
                 hipLaunchKernelGGL((pcgc_kernel<M, 3, 256, true, true, false, true>), dim3(s->B), dim3(T), pcg_fused_lds<M>(s), st, s->bf, s->N, s->B,
                                    s->p.max_pcg_iters, sqp_iter, 0, dt);
             else

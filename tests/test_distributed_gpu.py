@@ -271,3 +271,61 @@ def test_replay_backs_off_to_per_iteration_counts_and_a_captured_solve_never_wai
     g.replay()
     torch.cuda.synchronize()
     np.testing.assert_array_equal(xu.cpu().numpy(), eager["XU"])
+
+
+@pytest.mark.parametrize("ratio", [0.5, 1.0], ids=["replay", "no-replay"])
+def test_the_verdict_of_a_deferred_solve_is_taken_by_the_next_entry_point(ratio):
+    """Round 6: gato_solve_device on a sharded handle returns with the verdict PENDING -- the host is not held for the whole solve -- and the next entry
+    point that reads or changes what the solve reads or writes takes it (and replays exactly if the exit rule fired).  The device-pointer sequence of
+    bench.py's loop (reset_async, solve_device, a gather that does NOT take the verdict, copy_final_merit_device that does) on the shard that holds the
+    early convergers of the mixed batch: nothing is counted as settled before the merit copy, the results are the unsharded solve's bits afterwards --
+    through the replay at ratio 0.5, without one at ratio 1 -- and a second solve enqueued straight behind it (reset_async settles first) repeats them."""
+    from gato_amd._lib import NativeSolver
+    from gato_amd.bsqp.config import DEFAULT_SOLVER_PARAMS
+    from mixed_batch import mixed_problem
+    from oracle import oracle as O
+    if os.environ.get("GATO_GRAPH", "0") not in ("", "0"):
+        pytest.skip("a suite run under GATO_GRAPH=1 is about the host-buffer solve")
+    N, kinds = 32, "EUPPEUFFFFFF"
+    B, H = len(kinds), 6
+    p = dict(DEFAULT_SOLVER_PARAMS, max_sqp_iters=6, solve_ratio=ratio, pcg_tol=1e-8, max_pcg_iters=1000)
+    ee = lambda pl, q: O.ee(pl, q)[0]  # noqa: E731
+    pr = mixed_problem("indy7", N, kinds=kinds, ee=ee)
+    one = NativeSolver("indy7", N, B, dt=0.01, **p)
+    one.set_f_ext_batch(pr["f_ext"]); one.set_cost_weights_batch(pr["w"])
+    ref = one.solve(pr["xu"], 0.01, pr["x_s"], pr["ref"])
+    solved = np.cumsum(ref["pcg_iters_all"] == 0, axis=0) > 0
+    sh = mixed_problem("indy7", N, kinds=kinds, ee=ee, rows=(0, H))
+    s = NativeSolver("indy7", N, H, dt=0.01, **p)
+    s.set_f_ext_batch(sh["f_ext"]); s.set_cost_weights_batch(sh["w"])
+    s.debug_set_remote_solved(solved[:, H:].sum(axis=1).astype(np.uint32), B)
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.current_stream().cuda_stream
+    xu0 = torch.from_numpy(sh["xu"]).to(dev)
+    xs, rf = torch.from_numpy(sh["x_s"]).to(dev), torch.from_numpy(sh["ref"]).to(dev)
+    merit = torch.zeros(H, device=dev)
+    for rep in range(2):
+        xu = xu0.clone()
+        s.reset_async(True, True, st)            # (second pass: takes nothing -- the first pass's verdict was taken by its merit copy)
+        before = s.shard_stats()
+        s.solve_device(xu.data_ptr(), 0.01, xs.data_ptr(), rf.data_ptr(), st)
+        assert s.shard_stats() == before         # enqueued, not settled: neither counted as a speculative solve nor replayed yet
+        s.copy_final_merit_device(merit.data_ptr(), st)   # the next entry point on the handle: the verdict, the replay if the rule fired, then the copy
+        after = s.shard_stats()
+        assert after["deferred_solves"] == before["deferred_solves"] + 1 and after["replays"] == before["replays"] + (1 if ratio == 0.5 else 0), (before, after)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(xu.cpu().numpy(), ref["XU"][:H])
+        np.testing.assert_array_equal(merit.cpu().numpy(), ref["final_merit"][:H])
+        r = s.stats()
+        np.testing.assert_array_equal(r["pcg_iters_all"], ref["pcg_iters_all"][:, :H])
+        assert r["iters_done"] == ref["iters_done"]
+        if ratio == 0.5:
+            break    # (after a replay the next 8 solves count per iteration: test_replay_backs_off_...; the second pass is about the no-replay path)
+    # the getters take a pending verdict too: solve_device straight into stats()
+    if ratio == 1.0:
+        xu = xu0.clone()
+        s.reset_async(True, True, st)
+        s.solve_device(xu.data_ptr(), 0.01, xs.data_ptr(), rf.data_ptr(), st)
+        r = s.stats()                            # gato_get_*: sync_last -> settle -> drain
+        np.testing.assert_array_equal(xu.cpu().numpy(), ref["XU"][:H])
+        np.testing.assert_array_equal(r["final_merit"], ref["final_merit"][:H])

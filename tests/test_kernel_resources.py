@@ -15,7 +15,8 @@ CSRC = os.path.join(ROOT, "gato_amd", "csrc")
 
 # kernel (regex on the mangled name) -> (max VGPRs, max AGPRs, max scratch bytes per lane)
 BUDGETS = {
-    r"pcgc_kernelINS_5Indy7ELi3ELi256ELb1ELb1ELb0ELb1E": (256, 0, 0),      # C2's PCG: fused Schur + fold, single-lane form, every thread owns rows (N a multiple of 16)
+    r"pcgc_kernelINS_5Indy7ELi3ELi128ELb1ELb1ELb0ELb1E": (256, 0, 0),      # C2's PCG AS LAUNCHED since round 6 (N = 32: exactly two wavefronts, block_sum<.., TWO>): four trajectories per CU
+    r"pcgc_kernelINS_5Indy7ELi3ELi256ELb1ELb1ELb0ELb1E": (256, 0, 0),      # the same kernel for N = 64: fused Schur + fold, single-lane form, every thread owns rows (N a multiple of 16)
     r"pcgc_kernelINS_5Indy7ELi3ELi256ELb1ELb1ELb0ELb0E": (256, 16, 0),     # ... its masked form (N = 4, 8): a few AGPR copies since the body became a device function (round 4), no scratch
     r"pcgc_kernelINS_5Indy7ELi3ELi256ELb1ELb1ELb1ELb[01]E": (256, 0, 0),   # pair form
     r"pcgs_kernelINS_6Iiwa14ELi512ELb1E": (256, 0, 64),                 # C3's PCG (symmetric half storage, fold)
