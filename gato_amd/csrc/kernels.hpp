@@ -1428,7 +1428,10 @@ GATO_DEV float wave_sum(float v)
 template<int PARTS = 4, bool TWO = false> GATO_DEV float block_sum(float v, float* part, unsigned tx = threadIdx.x)
 {
     v = wave_sum(v);
-    if ((tx & 63) == 0) part[tx >> 6] = v;
+    // EVERY lane stores the wavefront's sum (the same value to the same address: one LDS write, no conflict) instead of lane 0 under an exec mask: the
+    // s_and_saveexec / s_cbranch_execz pair and the three adds it guarded sat on the dependent chain in front of the barrier -- C2 +1.9 %, same bits
+    // (round 6, profiles/r06_c2_micro_variants.json)
+    part[tx >> 6] = v;
     __syncthreads();
     if constexpr (TWO) {
         const real2 a2 = reinterpret_cast<const real2*>(part)[0];
@@ -2059,7 +2062,6 @@ GATO_DEV void pcgc_body(const Buffers& bf, int N, int B, int b, unsigned tx, uns
             const float* wb = vb + kb * NX + HC * h;
             float* oa = va + NX + rr;
             float* ob = vb + NX + rr;
-            const bool lead = (tx & 63) == 0;
             const int wv = tx >> 6;
             for (int i = tx; i < NX; i += TT) {
                 va[i] = 0.f; vb[i] = 0.f;
@@ -2084,7 +2086,7 @@ GATO_DEV void pcgc_body(const Buffers& bf, int N, int B, int b, unsigned tx, uns
                 loc += rv[u] * zv[u];
             }
             loc = wave_sum_pairs(loc);
-            if (lead) partA[wv] = loc;
+            partA[wv] = loc;   // every lane, the same value: see block_sum
             __syncthreads();
             float rho = read_parts(partA);
             if (!(fabsf(rho) < abs_tol)) {
@@ -2102,7 +2104,7 @@ GATO_DEV void pcgc_body(const Buffers& bf, int N, int B, int b, unsigned tx, uns
                         loc += pv[u] * acc[u];
                     }
                     loc = wave_sum_pairs(loc);
-                    if (lead) partB[wv] = loc;
+                    partB[wv] = loc;
                     __syncthreads();
                     const float pAp = read_parts(partB);
                     const float alpha = pcg_div(rho, pAp);
@@ -2122,7 +2124,7 @@ GATO_DEV void pcgc_body(const Buffers& bf, int N, int B, int b, unsigned tx, uns
                         loc += rv[u] * zv[u];
                     }
                     loc = wave_sum_pairs(loc);
-                    if (lead) partA[wv] = loc;
+                    partA[wv] = loc;   // every lane, the same value: see block_sum
                     __syncthreads();
                     const float rho_new = read_parts(partA);
                     if (fabsf(rho_new) < (abs_tol + eps * rho_init)) break;
@@ -2459,7 +2461,7 @@ __global__ __launch_bounds__(MAXT, 2) void pcgs_kernel(Buffers bf, int N, int B,
                 for (int i = 0; i < HR; i++) dotc = __builtin_fmaf(acc[i], vown[i], dotc);
             }
             dotc = wave_sum(dotc);
-            if ((t & 63) == 0) part[t >> 6] = dotc;
+            part[t >> 6] = dotc;   // every lane, the same value (block_sum: no exec-mask branch in front of the barrier)
             __syncthreads();
             if (mainrole) {
                 const float* t0 = tbuf + ((k + 1) * 2 + 0) * NX + h * HR;
