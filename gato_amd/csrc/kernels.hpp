@@ -1457,6 +1457,23 @@ template<int NX> GATO_DEV void load_btd_row(float* dst, const float* __restrict_
     load_vec<NX, NX>(dst + 2 * NX, base + 2 * BLK);
 }
 
+// The tail of a PCG iteration (pcg.cuh:127-141): beta = rho' / rho and p = z + beta p are formed BEFORE the exit test is branched on -- the quotient's
+// v_rcp_f32 does not depend on rho' and issues while the partial sums are still in flight, the three FMAs issue beside the compare instead of
+// behind the branch -- and are thrown away on the exit path (p is dead there).  Same arithmetic, same bits; C2 +0.7 % (round 6,
+// profiles/r06_c2_chain3.json).  The empty asm keeps the compiler from sinking the FMAs back behind the branch.
+#define GATO_PCG_TAIL(R, pv, zv, rho, rho_new, exit_thresh)                                  \
+    {                                                                                         \
+        const float beta_ = pcg_div(rho_new, rho);                                            \
+        float pn_[R];                                                                         \
+        _Pragma("unroll") for (int u_ = 0; u_ < R; u_++) {                                    \
+            pn_[u_] = zv[u_] + beta_ * pv[u_];                                                \
+            asm volatile("" : "+v"(pn_[u_]));                                                 \
+        }                                                                                     \
+        if (fabsf(rho_new) < (exit_thresh)) break;                                            \
+        rho = rho_new;                                                                        \
+        _Pragma("unroll") for (int u_ = 0; u_ < R; u_++) pv[u_] = pn_[u_];                    \
+    }
+
 // RPT rows per thread; STREAM = false keeps the thread's S / P^-1 rows in registers, true re-reads them from global memory
 // (L2 / Infinity Cache) for systems that do not fit one CU's register file (iiwa14 N = 128: 602 KB); MAXT = launch bound.
 template<class M, int RPT, bool STREAM, int MAXT>
@@ -1585,11 +1602,7 @@ __global__ __launch_bounds__(MAXT) void pcg_kernel(Buffers bf, int N, int B, uin
                     loc += rv[u] * zv[u];
                 }
                 const float rho_new = block_sum(loc, partA);
-                if (fabsf(rho_new) < (abs_tol + eps * rho_init)) break;
-                const float beta = pcg_div(rho_new, rho);
-                rho = rho_new;
-#pragma unroll
-                for (int u = 0; u < RPT; u++) pv[u] = zv[u] + beta * pv[u];
+                GATO_PCG_TAIL(RPT, pv, zv, rho, rho_new, abs_tol + eps * rho_init)
             }
 #pragma unroll
             for (int u = 0; u < RPT; u++)
@@ -2127,11 +2140,7 @@ GATO_DEV void pcgc_body(const Buffers& bf, int N, int B, int b, unsigned tx, uns
                     partA[wv] = loc;   // every lane, the same value: see block_sum
                     __syncthreads();
                     const float rho_new = read_parts(partA);
-                    if (fabsf(rho_new) < (abs_tol + eps * rho_init)) break;
-                    const float beta = pcg_div(rho_new, rho);
-                    rho = rho_new;
-#pragma unroll
-                    for (int u = 0; u < RPT; u++) pv[u] = zv[u] + beta * pv[u];
+                    GATO_PCG_TAIL(RPT, pv, zv, rho, rho_new, abs_tol + eps * rho_init)
                 }
                 if (owner) store_vec<RPT, RPT>(lam + NX + rr, xv);
             }
@@ -2202,11 +2211,7 @@ GATO_DEV void pcgc_body(const Buffers& bf, int N, int B, int b, unsigned tx, uns
                     loc += rv[u] * zv[u];
                 }
                 const float rho_new = block_sum<PARTS, TWO>(loc, partA, tx);
-                if (fabsf(rho_new) < (abs_tol + eps * rho_init)) break;
-                const float beta = pcg_div(rho_new, rho);
-                rho = rho_new;
-#pragma unroll
-                for (int u = 0; u < RPT; u++) pv[u] = zv[u] + beta * pv[u];
+                GATO_PCG_TAIL(RPT, pv, zv, rho, rho_new, abs_tol + eps * rho_init)
             }
             if (have) store_vec<RPT, RPT>(lam + NX + rr, xv);
         }
@@ -2510,11 +2515,7 @@ __global__ __launch_bounds__(MAXT, 2) void pcgs_kernel(Buffers bf, int N, int B,
                 if (mainrole) store_vec<HR, 1>(vb + own, rv);
                 __syncthreads();
                 const float rho_new = matvec(vb, winb, yes{}, zv, rv, partA);  // z = P^-1 r and r^T z
-                if (fabsf(rho_new) < (abs_tol + eps * rho_init)) break;
-                const float beta = pcg_div(rho_new, rho);
-                rho = rho_new;
-#pragma unroll
-                for (int i = 0; i < HR; i++) pv[i] = zv[i] + beta * pv[i];
+                GATO_PCG_TAIL(HR, pv, zv, rho, rho_new, abs_tol + eps * rho_init)
             }
             if (mainrole) {
 #pragma unroll
