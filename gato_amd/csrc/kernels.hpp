@@ -1457,21 +1457,24 @@ template<int NX> GATO_DEV void load_btd_row(float* dst, const float* __restrict_
     load_vec<NX, NX>(dst + 2 * NX, base + 2 * BLK);
 }
 
-// The tail of a PCG iteration (pcg.cuh:127-141): beta = rho' / rho and p = z + beta p are formed BEFORE the exit test is branched on -- the quotient's
-// v_rcp_f32 does not depend on rho' and issues while the partial sums are still in flight, the three FMAs issue beside the compare instead of
-// behind the branch -- and are thrown away on the exit path (p is dead there).  Same arithmetic, same bits; C2 +0.7 % (round 6,
-// profiles/r06_c2_chain3.json).  The empty asm keeps the compiler from sinking the FMAs back behind the branch.
-#define GATO_PCG_TAIL(R, pv, zv, rho, rho_new, exit_thresh)                                  \
-    {                                                                                         \
-        const float beta_ = pcg_div(rho_new, rho);                                            \
-        float pn_[R];                                                                         \
-        _Pragma("unroll") for (int u_ = 0; u_ < R; u_++) {                                    \
-            pn_[u_] = zv[u_] + beta_ * pv[u_];                                                \
-            asm volatile("" : "+v"(pn_[u_]));                                                 \
-        }                                                                                     \
-        if (fabsf(rho_new) < (exit_thresh)) break;                                            \
-        rho = rho_new;                                                                        \
-        _Pragma("unroll") for (int u_ = 0; u_ < R; u_++) pv[u_] = pn_[u_];                    \
+// The tail of a PCG iteration (pcg.cuh:127-141) and the SHAPE of its loop (round 6).  beta = rho' / rho and p = z + beta p are formed BEFORE the exit
+// test is branched on -- the quotient's v_rcp_f32 does not depend on rho' and issues while the partial sums are still in flight, the FMAs issue beside the
+// compare -- p is updated IN PLACE by one three-address v_fma_f32 per entry (left to itself the compiler takes the two-address v_fmac_f32 into z's register
+// and copies it back: four v_mov_b32 on the dependent chain), and the two ways out of the loop -- the test and the iteration cap -- are ONE branch.  p is
+// dead on the way out.  Same arithmetic, same bits.  The loop is `if (max_iters > 0) for (;;) { iters++; ... GATO_PCG_TAIL(...) }`: in that single-exit
+// form the compiler issues all nine 16-byte window reads of a product up front (255 registers) where the two-exit loop staged them 4 + 2 + 2 + 1 behind
+// four waits (246 registers) -- ~300 cycles per iteration: C2's PCG launch 119.5 -> 104.5 us, the headline +9.8 % (profiles/r06_c2_chain4.json).
+GATO_DEV void pcg_p_update(float& p, float beta, float z)
+{
+    if constexpr (sizeof(float) == 4) asm volatile("v_fma_f32 %0, %1, %0, %2" : "+v"(p) : "v"(beta), "v"(z));
+    else { p = z + beta * p; asm volatile("" : "+v"(p)); }
+}
+#define GATO_PCG_TAIL(R, pv, zv, rho, rho_new, exit_thresh, iters, max_iters)                   \
+    {                                                                                            \
+        const float beta_ = pcg_div(rho_new, rho);                                               \
+        _Pragma("unroll") for (int u_ = 0; u_ < R; u_++) pcg_p_update(pv[u_], beta_, zv[u_]);    \
+        if ((fabsf(rho_new) < (exit_thresh)) | ((iters) == (max_iters))) break;                  \
+        rho = rho_new;                                                                           \
     }
 
 // RPT rows per thread; STREAM = false keeps the thread's S / P^-1 rows in registers, true re-reads them from global memory
@@ -1573,7 +1576,7 @@ __global__ __launch_bounds__(MAXT) void pcg_kernel(Buffers bf, int N, int B, uin
         float rho = block_sum(loc, partA);
         if (!(fabsf(rho) < abs_tol)) {
             const float rho_init = fabsf(rho);
-            for (uint32_t it = 0; it < max_iters; it++) {
+            if (max_iters > 0) for (;;) {
                 iters++;
 #pragma unroll
                 for (int u = 0; u < RPT; u++)
@@ -1602,7 +1605,7 @@ __global__ __launch_bounds__(MAXT) void pcg_kernel(Buffers bf, int N, int B, uin
                     loc += rv[u] * zv[u];
                 }
                 const float rho_new = block_sum(loc, partA);
-                GATO_PCG_TAIL(RPT, pv, zv, rho, rho_new, abs_tol + eps * rho_init)
+                GATO_PCG_TAIL(RPT, pv, zv, rho, rho_new, abs_tol + eps * rho_init, iters, max_iters)
             }
 #pragma unroll
             for (int u = 0; u < RPT; u++)
@@ -2104,7 +2107,7 @@ GATO_DEV void pcgc_body(const Buffers& bf, int N, int B, int b, unsigned tx, uns
             float rho = read_parts(partA);
             if (!(fabsf(rho) < abs_tol)) {
                 const float rho_init = fabsf(rho);
-                for (uint32_t it = 0; it < max_iters; it++) {
+                if (max_iters > 0) for (;;) {
                     iters++;
                     if (owner) store_vec<RPT, RPT>(oa, pv);
                     __syncthreads();
@@ -2140,7 +2143,7 @@ GATO_DEV void pcgc_body(const Buffers& bf, int N, int B, int b, unsigned tx, uns
                     partA[wv] = loc;   // every lane, the same value: see block_sum
                     __syncthreads();
                     const float rho_new = read_parts(partA);
-                    GATO_PCG_TAIL(RPT, pv, zv, rho, rho_new, abs_tol + eps * rho_init)
+                    GATO_PCG_TAIL(RPT, pv, zv, rho, rho_new, abs_tol + eps * rho_init, iters, max_iters)
                 }
                 if (owner) store_vec<RPT, RPT>(lam + NX + rr, xv);
             }
@@ -2183,7 +2186,7 @@ GATO_DEV void pcgc_body(const Buffers& bf, int N, int B, int b, unsigned tx, uns
         const bool entered = !(fabsf(rho) < abs_tol);
         if (entered) {
             const float rho_init = fabsf(rho);
-            for (uint32_t it = 0; it < max_iters; it++) {
+            if (max_iters > 0) for (;;) {
                 iters++;
                 if (have) store_vec<RPT, RPT>(oa, pv);
                 __syncthreads();
@@ -2211,7 +2214,7 @@ GATO_DEV void pcgc_body(const Buffers& bf, int N, int B, int b, unsigned tx, uns
                     loc += rv[u] * zv[u];
                 }
                 const float rho_new = block_sum<PARTS, TWO>(loc, partA, tx);
-                GATO_PCG_TAIL(RPT, pv, zv, rho, rho_new, abs_tol + eps * rho_init)
+                GATO_PCG_TAIL(RPT, pv, zv, rho, rho_new, abs_tol + eps * rho_init, iters, max_iters)
             }
             if (have) store_vec<RPT, RPT>(lam + NX + rr, xv);
         }
@@ -2501,7 +2504,7 @@ __global__ __launch_bounds__(MAXT, 2) void pcgs_kernel(Buffers bf, int N, int B,
         for (int i = 0; i < HR; i++) pv[i] = zv[i];
         if (!(fabsf(rho) < abs_tol)) {
             const float rho_init = fabsf(rho);
-            for (uint32_t it = 0; it < max_iters; it++) {
+            if (max_iters > 0) for (;;) {
                 iters++;
                 if (mainrole) store_vec<HR, 1>(va + own, pv);
                 __syncthreads();
@@ -2515,7 +2518,7 @@ __global__ __launch_bounds__(MAXT, 2) void pcgs_kernel(Buffers bf, int N, int B,
                 if (mainrole) store_vec<HR, 1>(vb + own, rv);
                 __syncthreads();
                 const float rho_new = matvec(vb, winb, yes{}, zv, rv, partA);  // z = P^-1 r and r^T z
-                GATO_PCG_TAIL(HR, pv, zv, rho, rho_new, abs_tol + eps * rho_init)
+                GATO_PCG_TAIL(HR, pv, zv, rho, rho_new, abs_tol + eps * rho_init, iters, max_iters)
             }
             if (mainrole) {
 #pragma unroll

@@ -25,7 +25,8 @@ BUDGETS = {
     r"kkt_kernelINS_6Iiwa14E": (256, 0, 0),                            # 4 wavefronts per workgroup (columns {0,5,6} {1,3} {2,4} + costs): two workgroups per CU
     r"step_kernelINS_5Indy7ELi512E": (128, 0, 0),                        # 4 wavefronts per SIMD: every C2 workgroup resident
     r"step_kernelINS_6Iiwa14ELi(512|1024)E": (128, 0, 64),                # iiwa14: 44 bytes of scratch since the row-per-lane dz (160 with dz_knot)
-    r"pcgc_kernelINS_6Iiwa14ELi2ELi512ELb1ELb0ELb0ELb1E": (208, 0, 0),   # C5's PCG as launched (FULL): 204 registers
+    r"pcgc_kernelINS_6Iiwa14ELi2ELi512ELb1ELb0ELb0ELb1E": (240, 0, 0),   # C5's PCG as launched (FULL): 231 registers since the single-exit loop of round 6 (all window reads of a
+                                                                         # product in flight at once; 204 before); 7 wavefronts on 4 SIMDs: two per SIMD = 256 is the bound that matters
     r"schur1_kernelINS_6Iiwa14ELb0E": (128, 0, 0),                       # 4 wavefronts per SIMD (LDS allows no more); with the staged block stores it needs the pin on the
                                                                          # theta columns (kernels.hpp) or the allocator takes 256 + 132
     r"btd_cr_kernelINS_\w+ELi16E": (128, 0, 0),                          # cyclic reduction, 16 wavefronts per workgroup: 1024 threads need <= 128
