@@ -1425,13 +1425,19 @@ GATO_DEV float wave_sum(float v)
 // The other slots are exact zeros, so (a.x + a.y) + (0 + 0) has the same bits -- two dependent adds and half the read off the chain behind every
 // reduction barrier.  A COMPILE-TIME switch: the same thing behind a wavefront-uniform run-time branch measured 0.75 % SLOWER than not having it (the
 // branch sits on that same chain), the instantiation +0.8 % (profiles/r06_c2_two_form_abc.json: three builds round-robin on one box, same bits)
-template<int PARTS = 4, bool TWO = false> GATO_DEV float block_sum(float v, float* part, unsigned tx = threadIdx.x)
+// shadow: work of the caller that does not depend on the sum, issued between the partial's store and the barrier -- i.e. while the store completes
+// (s_waitcnt lgkmcnt(0) sits in front of s_barrier).  The PCG loops put the x update there: sunk by the compiler it sat on the dependent chain in front of
+// the next store (C2 +0.4 %, same bits: profiles/r06_c2_chain5.json)
+struct NoShadow { GATO_DEV void operator()() const {} };
+template<int PARTS = 4, bool TWO = false, class F = NoShadow> GATO_DEV float block_sum(float v, float* part, unsigned tx = threadIdx.x, F shadow = F())
 {
     v = wave_sum(v);
     // EVERY lane stores the wavefront's sum (the same value to the same address: one LDS write, no conflict) instead of lane 0 under an exec mask: the
     // s_and_saveexec / s_cbranch_execz pair and the three adds it guarded sat on the dependent chain in front of the barrier -- C2 +1.9 %, same bits
     // (round 6, profiles/r06_c2_micro_variants.json)
     part[tx >> 6] = v;
+    asm volatile("" ::: "memory");
+    shadow();   // work that does not depend on the sum: issued while the store completes, in front of the barrier's wait
     __syncthreads();
     if constexpr (TWO) {
         const real2 a2 = reinterpret_cast<const real2*>(part)[0];
@@ -2200,10 +2206,7 @@ GATO_DEV void pcgc_body(const Buffers& bf, int N, int B, int b, unsigned tx, uns
                 const float pAp = block_sum<PARTS, TWO>(loc, partB, tx);
                 const float alpha = pcg_div(rho, pAp);
 #pragma unroll
-                for (int u = 0; u < RPT; u++) {
-                    xv[u] += alpha * pv[u];
-                    rv[u] -= alpha * acc[u];
-                }
+                for (int u = 0; u < RPT; u++) rv[u] -= alpha * acc[u];
                 if (have) store_vec<RPT, RPT>(ob, rv);
                 __syncthreads();
                 pdot(wb, acc);  // z = P^-1 r
@@ -2213,7 +2216,14 @@ GATO_DEV void pcgc_body(const Buffers& bf, int N, int B, int b, unsigned tx, uns
                     zv[u] = have ? acc[u] : 0.f;
                     loc += rv[u] * zv[u];
                 }
-                const float rho_new = block_sum<PARTS, TWO>(loc, partA, tx);
+                // the x update rides in the shadow of the partial sum's store (it needs alpha and the OLD p: both still live here)
+                auto xup = [&]() {
+                    float al = alpha;
+                    asm volatile("" : "+v"(al));
+#pragma unroll
+                    for (int u = 0; u < RPT; u++) { xv[u] += al * pv[u]; asm volatile("" : "+v"(xv[u])); }
+                };
+                const float rho_new = block_sum<PARTS, TWO>(loc, partA, tx, xup);
                 GATO_PCG_TAIL(RPT, pv, zv, rho, rho_new, abs_tol + eps * rho_init, iters, max_iters)
             }
             if (have) store_vec<RPT, RPT>(lam + NX + rr, xv);
