@@ -44,7 +44,8 @@ def kernels_block(pmc):
 
 def bench_block(tag):
     rows = ["| configuration | traj-SQP-iter/s | ms per solve | dominant kernel | µs / launch | roof (bound) | CPU port, host cores |", "|---|---|---|---|---|---|---|"]
-    for name, f in (("C2 indy7 N=32 B=1024 (headline)", "%s_bench.json"), ("C3 iiwa14 N=128 B=256", "%s_bench_c3.json"), ("C5 shard iiwa14 N=64 B=512, sweep", "%s_bench_c5.json")):
+    for name, f in (("C2 indy7 N=32 B=1024 (headline)", "%s_bench.json"), ("C3 iiwa14 N=128 B=256", "%s_bench_c3.json"), ("C5 shard iiwa14 N=64 B=512, sweep", "%s_bench_c5.json"),
+                    ("one device at the C4 global batch: indy7 N=32 B=8192", "%s_bench_b8192.json"), ("C2 as the driver runs it (20 timed solves)", "%s_bench_driver_style.json")):
         j = load(os.path.join(ROOT, "profiles", f % tag))
         if not j:
             continue
@@ -55,13 +56,16 @@ def bench_block(tag):
 
 
 def heatmap_block():
-    """the reference's MPC solve-time heat-map next to this library's (profiles/r06_mpc_heatmap_{pcg,direct}.json, tools/mpc_heatmap.py --solve-wall).
+    """the reference's MPC solve-time heat-map next to this library's (profiles/r06h_mpc_heatmap_{pcg,direct}.json, tools/mpc_heatmap.py --solve-wall).
     THREE figures per cell: the host wall clock around the solve alone, device-synchronised on both sides -- the reference's own `sqp_time_us`
     (bsqp.cuh:109,185), which is what its published heat-map shows, and therefore the column compared with it --, the device time between hipEvents
     around the solve's launches, and the host wall clock of the whole session step."""
     cells, pub = {}, {}
     for f in ("pcg", "direct"):
-        for c in json.load(open(os.path.join(ROOT, "profiles", "r06_mpc_heatmap_%s.json" % f))):
+        path = os.path.join(ROOT, "profiles", "r06h_mpc_heatmap_%s.json" % f)      # the round's final kernels
+        if not os.path.exists(path):
+            path = os.path.join(ROOT, "profiles", "r06_mpc_heatmap_%s.json" % f)   # the first measurement of the round (before the PCG chain work)
+        for c in json.load(open(path)):
             cells[(c["knots"], c["linear_solver"], c["batch"])] = c
             if c.get("published_ms") is not None:
                 pub[(c["knots"], c["batch"])] = c["published_ms"]
