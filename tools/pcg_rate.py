@@ -41,4 +41,4 @@ for plant, N, B, env, what in cfgs:
     slope = (t[90] - t[10]) / 80.0
     out.append(dict(plant=plant, N=N, B=B, env=env, what=what, launch_us=t, us_per_iteration=slope, prologue_us=t[10] - 10 * slope))
     print("%-70s B=%4d  launch us %s   %.3f us / iteration, prologue %.1f us" % (what, B, {k: round(v, 1) for k, v in t.items()}, slope, t[10] - 10 * slope), flush=True)
-json.dump(out, open(os.path.join(ROOT, "gpurun_out", "r05_pcg_rate.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(ROOT, "gpurun_out", "r06_pcg_rate.json"), "w"), indent=1)
