@@ -482,17 +482,18 @@ template<class M> static int plan_pcg(GatoSolver* s)
                            grant_lds(reinterpret_cast<const void*>(&pcgc_kernel<M, 3, 128, true, true, false, true>), pcg_fused_lds<M>(s));
     }
     s->pcg_fused = fused ? 1 : 0;
-    // Pair form of the fused kernel: two lanes per row group (twice the threads, half of the columns each; same bits).  A PCG iteration
-    // is a per-wavefront instruction chain, so halving a wavefront's share shortens it (0.79 vs 0.97 us per iteration) -- but the
-    // prologue still holds whole rows, the workgroup needs twice the registers, and only half as many trajectories fit a CU: it pays
-    // when ALL trajectories are resident at once (B <= 2 per CU at N = 32: -6 .. -13 % per solve for B <= 512, +7 % at B = 1024 where
-    // it would run in two rounds).  GATO_PCG_PAIR = 0 / 1 forces the choice.
+    // Pair form of the fused kernel: two lanes per row group (twice the threads, half of the columns each; same bits).  Rounds 2-5 chose it wherever
+    // the whole batch is resident in it (B <= 512 at N = 32): halving a wavefront's share of the multiply-adds shortened the iteration (0.79 vs 0.97 us).
+    // Round 6 took ~300 cycles of exposed LDS latency and several branches out of the SINGLE-LANE loop (kernels.hpp: GATO_PCG_TAIL): it now iterates in
+    // 0.711 us alone against the pair form's 0.714 (profiles/r06_pcg_rate.txt) and is ahead by ~1 % on whole solves at every B <= 512 (its prologue is the
+    // lighter one).  So the pair form is OPT-IN now: GATO_PCG_PAIR = 1 (the two stay bit-identical: tests/test_gpu_parity.py).
     bool pair = false;
     if constexpr (NX == 12) {
         const int T2 = 2 * PcgcShape<NX, 3, 0>::threads(s->N * s->nx);
         const int cus = s->cus;
         const char* pe = getenv("GATO_PCG_PAIR");
-        const bool want = pe ? atoi(pe) != 0 : (long)s->B * (T2 / 64) <= (long)cus * 8;   // 2 wavefronts per SIMD at 236 registers
+        const bool want = pe ? atoi(pe) != 0 : false;
+        (void)cus;
         pair = fused && want && T2 <= 256 && T2 >= 64 &&
                grant_lds(reinterpret_cast<const void*>(&pcgc_kernel<M, 3, 256, true, true, true>), pcg_fused_lds<M>(s)) &&
                grant_lds(reinterpret_cast<const void*>(&pcgc_kernel<M, 3, 256, true, true, true, true>), pcg_fused_lds<M>(s));

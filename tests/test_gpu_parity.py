@@ -476,8 +476,8 @@ def test_fused_kernels_equal_separate_launches(N, B, fstd, monkeypatch):
 
 @pytest.mark.parametrize("N,B,fstd", [(32, 24, 4.0), (16, 7, 2.0), (4, 3, 1.0), (8, 2, 0.0), (32, 600, 0.0)])
 def test_pair_form_of_the_pcg_kernel_equals_the_single_lane_form(N, B, fstd, monkeypatch):
-    """pcgc_kernel<.., PAIR> gives every row group to two lanes (half of the columns each; chosen when every trajectory of the batch is
-    resident in that form, B <= 512 at N = 32) -- the row sums associate as in the single-lane form and the wavefront sums run over the
+    """pcgc_kernel<.., PAIR> gives every row group to two lanes (half of the columns each; the default for B <= 512 at N = 32 in rounds 2-5, opt-in
+    through GATO_PCG_PAIR = 1 since the single-lane loop caught up with it in round 6) -- the row sums associate as in the single-lane form and the wavefront sums run over the
     same tree, so the batch size never changes a trajectory's bits: forced on and off, whole solves agree bit for bit."""
     from gato_amd._lib import NativeSolver
     p = dict(DEFAULT_SOLVER_PARAMS, max_sqp_iters=4)

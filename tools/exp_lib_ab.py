@@ -21,8 +21,10 @@ import numpy as np
 from gato_amd._lib import NativeSolver
 from gato_amd.bsqp.config import DEFAULT_SOLVER_PARAMS
 from gato_amd.bsqp.workloads import fig8_problem
-pr = fig8_problem("indy7", 32, 1024)
-s = NativeSolver("indy7", 32, 1024, dt=0.01, **dict(DEFAULT_SOLVER_PARAMS, max_sqp_iters=10))
+import os
+plant, N, B = os.environ.get("AB_PLANT", "indy7"), int(os.environ.get("AB_KNOTS", "32")), int(os.environ.get("AB_BATCH", "1024"))
+pr = fig8_problem(plant, N, B)
+s = NativeSolver(plant, N, B, dt=0.01, **dict(DEFAULT_SOLVER_PARAMS, max_sqp_iters=10))
 r = s.solve(pr["xu"], 0.01, pr["x_s"], pr["ref"])
 h = hashlib.sha256()
 for a in (r["XU"], s.read("lambda"), r["pcg_iters_all"], r["final_merit"], r["ls_step_size"]):
@@ -45,7 +47,12 @@ def main():
     ap.add_argument("--runs", type=int, default=5)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r06_c2_chain.json"))
+    ap.add_argument("--plant", default="indy7")
+    ap.add_argument("--knots", type=int, default=32)
+    ap.add_argument("--batch", type=int, default=1024)
     a = ap.parse_args()
+    os.environ.update(AB_PLANT=a.plant, AB_KNOTS=str(a.knots), AB_BATCH=str(a.batch))
+    cfg = ["--plant", a.plant, "--knots", str(a.knots), "--batch", str(a.batch)]
     libs = [("base", None)]
     for e in a.exp:
         name, _, path = e.rpartition("=")
@@ -60,7 +67,7 @@ def main():
         out[name] = {"library": lib or "gato_amd/csrc/libgato_hip.so", **run(env, [sys.executable, "-c", DIGEST]), "bench_values": [], "ms_per_solve": [], "pcg_launch_us": []}
     for _ in range(a.runs):                 # round robin: a drift of the box (clock, temperature) hits every build alike
         for name, _lib in libs:
-            b = run(envs[name], [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", str(a.steps), "--warmup", "10", "--no-cpu-baseline"])
+            b = run(envs[name], [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", str(a.steps), "--warmup", "10", "--no-cpu-baseline", *cfg])
             out[name]["bench_values"].append(b["value"]); out[name]["ms_per_solve"].append(b["ms_per_step"]); out[name]["pcg_launch_us"].append(b["roofline"]["avg_launch_us"])
     for name, _lib in libs:
         v = sorted(out[name]["bench_values"])
