@@ -56,13 +56,13 @@ def bench_block(tag):
 
 
 def heatmap_block():
-    """the reference's MPC solve-time heat-map next to this library's (profiles/r06h_mpc_heatmap_{pcg,direct}.json, tools/mpc_heatmap.py --solve-wall).
+    """the reference's MPC solve-time heat-map next to this library's (profiles/r06i_mpc_heatmap_{pcg,direct}.json, tools/mpc_heatmap.py --solve-wall).
     THREE figures per cell: the host wall clock around the solve alone, device-synchronised on both sides -- the reference's own `sqp_time_us`
     (bsqp.cuh:109,185), which is what its published heat-map shows, and therefore the column compared with it --, the device time between hipEvents
     around the solve's launches, and the host wall clock of the whole session step."""
     cells, pub = {}, {}
     for f in ("pcg", "direct"):
-        path = os.path.join(ROOT, "profiles", "r06h_mpc_heatmap_%s.json" % f)      # the round's final kernels
+        path = os.path.join(ROOT, "profiles", "r06i_mpc_heatmap_%s.json" % f)      # the round's final kernels
         if not os.path.exists(path):
             path = os.path.join(ROOT, "profiles", "r06_mpc_heatmap_%s.json" % f)   # the first measurement of the round (before the PCG chain work)
         for c in json.load(open(path)):
