@@ -8,6 +8,8 @@ One step = one pass of the hot path over one batch: reset_dual() + reset_rho() +
 DEFAULT_SOLVER_PARAMS otherwise) on B = 1024 trajectories per GPU, inputs already resident in HBM, plus -- for N > 1 -- the
 solved count of the exit rule (deferred: ONE ncclAllReduce of the per-iteration count vector behind a speculative solve, an exact replay if the
 rule fired; GATO_SOLVED_COUNT=periter: a 4-byte ncclAllReduce in every SQP iteration) and the all-gather of iterates and merits over xGMI.
+The library leaves the verdict of a sharded solve to its NEXT entry point (gato_abi.h): the gather of solve n is enqueued between the launches of solve
+n + 1 and that solve's merit copy (which takes the verdict), so it runs on the communication stream beside solve n + 1 and the host never holds the device idle.
 value = sum over ranks of B * iterations / wall time (max over ranks).  Rank 0 prints ONE JSON line.
 
     --workload hparam --plant iiwa14 --knots 64 --batch 512     BASELINE config C5 (the hyper-parameter sweep): rank g solves shard g =
