@@ -1,4 +1,8 @@
-import sys; sys.path.insert(0, "/root/repo")
+"""PCG iteration counts and the stage clock of one-iteration indy7 N = 128 solves at B = 1 / 8 from the reset state (where the N = 128, B <= 8 cells of the
+MPC heat-map spend their time: DESIGN.md section 4).  Runs on the MI355X box -> profiles/r06_n128_small_batch.txt."""
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from gato_amd._lib import NativeSolver
 from gato_amd.bsqp.config import DEFAULT_SOLVER_PARAMS
