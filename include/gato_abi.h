@@ -249,6 +249,8 @@ int gato_gather_results(GatoSolver* s, const gato_real* d_local, gato_real* d_al
  *       is what the split is for: between gato_solve_device and the next entry point the host is free, and bench.py enqueues the PREVIOUS solve's
  *       gather there, with the device busy (the verdict taken inside gato_solve_device left the device idle for every host call between two
  *       solves: 87 us per 1.7 ms solve at C4, profiles/r06_scaling_prediction.json).  gato_solve and gato_mpc_step take the verdict themselves.
+ *       The wait itself is a spin on the sequence number in pinned memory (one host core per rank is busy while its device finishes the solve; the stream
+ *       is queried every ~1e6 spins, so a device fault ends it with an error instead of a hang).
  *   GATO_COUNT_PER_ITERATION        one 4-byte all-reduce between the PCG launch and the step launch of every SQP iteration, no host wait
  *       (round 3's form; also what a hipGraph capture of a sharded solve uses).
  * A solve on a stream that is being CAPTURED (gato_solve_device under hipStreamBeginCapture) always counts per iteration: the deferred form's
